@@ -1,0 +1,215 @@
+/*
+ * rtd.h — C ABI of the MI355X pencil-beam proton dose engine.
+ *
+ * This is the drop-in boundary for the reference's single hot-path entry point
+ *
+ *     void cudaWrapperProtons(HostPinnedImage3D<float>* imVol, HostPinnedImage3D<float>* doseVol,
+ *                             const std::vector<BeamSettings> beams, const EnergyStruct iddData,
+ *                             std::ostream& outStream);            (reference src/kernel_wrapper.cuh:161)
+ *
+ * Every struct below is the plain-C image of one reference host type; every function cites the
+ * part of the reference it replaces. No C++/STL/torch types cross this boundary: plain pointers,
+ * sizes and PODs only. All arrays are x-fastest ("[z][y][x]"), float32, exactly as in the reference.
+ *
+ * Threading: one handle per host thread; a handle owns one HIP device, one stream and all device
+ * memory it allocates. Functions return RTD_OK (0) or a negative rtd_status; rtd_last_error()
+ * returns the message (the reference throws std::runtime_error / const char* instead,
+ * src/cuda_errchk.cu:11-22, src/kernel_wrapper.cu:965).
+ */
+#ifndef RTD_H
+#define RTD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTD_ABI_VERSION 1
+
+typedef enum rtd_status {
+    RTD_OK = 0,
+    RTD_ERR_INVALID_ARG = -1,     /* null pointer, zero dimension, empty energy list (vector_find.h:24) */
+    RTD_ERR_HIP = -2,             /* a HIP runtime call or kernel launch failed (cuda_errchk.cu:11-22) */
+    RTD_ERR_RADIUS_OVERFLOW = -3, /* "Found larger than allowed kernel superposition radius" (kernel_wrapper.cu:965) */
+    RTD_ERR_NOT_READY = -4,       /* CT or LUTs not set before compute */
+    RTD_ERR_IO = -5,              /* LUT directory unreadable (energy_reader.cpp:21-24) */
+    RTD_ERR_NO_DEVICE = -6        /* no HIP device: the engine has no CPU fallback */
+} rtd_status;
+
+/* Float3AffineTransform (src/float3_affine_transform.cuh): y = M x + v, M row-major. */
+typedef struct rtd_affine {
+    float m[9];
+    float v[3];
+} rtd_affine;
+
+/* Float3IdxTransform (src/float3_idx_transform.cuh): y = x*delta + offset, component-wise. */
+typedef struct rtd_idx_transform {
+    float delta[3];
+    float offset[3];
+} rtd_idx_transform;
+
+/*
+ * BeamSettings (src/beam_settings.h:101-109), all nine fields.
+ * spot_weights: [n_layers][spot_ny][spot_nx] particle numbers (beam_settings.h:21). Caller-owned; the
+ * engine never frees it (the reference deletes it, kernel_wrapper.cu:856 — the C++ shim can mimic that).
+ */
+typedef struct rtd_beam {
+    const float* spot_weights;
+    uint32_t spot_nx, spot_ny, n_layers;
+    const float* energies;            /* [n_layers] MeV/u */
+    const float* spot_sigmas;         /* [n_layers][2] (sigma_x, sigma_y) mm at iso in air */
+    float ray_spacing[2];             /* mm between adjacent rays at iso */
+    uint32_t tracer_steps;            /* number of ray-trace steps */
+    float source_dist[2];             /* apparent source-to-iso distance in x and y, mm; may be +inf */
+    rtd_idx_transform spot_idx_to_gantry; /* delta.z = (negative) step length, offset.z = start depth */
+    rtd_affine gantry_to_im_idx;      /* gantry mm -> CT voxel index */
+    rtd_affine gantry_to_dose_idx;    /* gantry mm -> dose voxel index */
+} rtd_beam;
+
+/* EnergyStruct (src/energy_struct.h:13-31). cidd_matrix is [n_energies][n_energy_samples]. */
+typedef struct rtd_luts {
+    int32_t n_energy_samples;
+    int32_t n_energies;
+    const float* energies_per_u;   /* [n_energies] ascending */
+    const float* peak_depths;      /* [n_energies] mm */
+    const float* scale_facts;      /* [n_energies] samples per mm */
+    const float* cidd_matrix;      /* [n_energies*n_energy_samples] cumulative IDD */
+    int32_t n_density_samples;
+    float density_scale_fact;
+    const float* density_vector;   /* mass density vs (HU+1000)*scale */
+    int32_t n_sp_samples;
+    float sp_scale_fact;
+    const float* sp_vector;        /* relative stopping power vs (HU+1000)*scale */
+    int32_t n_rrl_samples;
+    float rrl_scale_fact;
+    const float* rrl_vector;       /* 1/X0 per unit density vs density*scale */
+} rtd_luts;
+
+/*
+ * The reference's compile-time physics switches (CMakeLists.txt:36-79) as run-time options.
+ * rtd_default_options() returns the reference defaults.
+ */
+typedef struct rtd_options {
+    int32_t dose_to_water;      /* DOSE_TO_WATER (ON)  kernel_wrapper.cu:314-318 */
+    int32_t nozzle;             /* NOZZLE (ON); 0 = NO_NOZZLE  fill_idd_and_sigma_params.cu:74-83 */
+    float bp_depth_cutoff;      /* BP_DEPTH_CUTOFF   1.05 */
+    float conv_sigma_cutoff;    /* CONV_SIGMA_CUTOFF 3.0  */
+    float ks_sigma_cutoff;      /* KS_SIGMA_CUTOFF   3.0  */
+    float ray_weight_cutoff;    /* RAY_WEIGHT_CUTOFF 1.0  */
+    int32_t fine_grained_timing;/* FINE_GRAINED_TIMING: per-stage hipEvent buckets */
+    int32_t reserved[4];
+} rtd_options;
+
+/*
+ * Per-field timing record; bucket names follow the reference's FINE_GRAINED_TIMING printout
+ * (kernel_wrapper.cu:1298-1307). All values in milliseconds, measured with hipEvents on the
+ * handle's stream. Only filled when options.fine_grained_timing != 0 (else total_ms only).
+ */
+typedef struct rtd_timing {
+    float raytracing_ms;          /* "Time to trace ... rays"                    */
+    float prepare_energy_loop_ms; /* plan + BEV zero + spot->ray convolution     */
+    float fill_idd_sigma_ms;      /* "Time depositing IDD and calculating sigma" */
+    float prepare_superp_ms;      /* tile radius classification + batching       */
+    float superp_ms;              /* "Time executing superposition"              */
+    float transforming_ms;        /* "Kernel time to transform ... voxels"       */
+    float total_ms;               /* first kernel to last kernel of the field    */
+    int32_t superp_launches;      /* number of superposition kernel launches     */
+    int32_t reserved[3];
+} rtd_timing;
+
+/* Geometry and cut-off scalars of the last computed field (for logs, tests and the roofline model). */
+typedef struct rtd_field_info {
+    uint32_t ray_dims[3];         /* primRayDims (W, H, L)  kernel_wrapper.cu:659 */
+    float ray_offset[3];          /* primRayOffset          kernel_wrapper.cu:654 */
+    float ray_res[3];             /* primRayRes             kernel_wrapper.cu:623 */
+    int32_t beam_first_inside;    /* kernel_wrapper.cu:781-784 */
+    int32_t beam_first_outside;   /* kernel_wrapper.cu:785-787 */
+    int32_t beam_first_guaranteed_passive; /* kernel_wrapper.cu:796 */
+    int32_t beam_first_calculated_passive; /* kernel_wrapper.cu:955-957 */
+    int32_t bbox_min[3];          /* kernel_wrapper.cu:1207 */
+    int32_t bbox_max[3];          /* kernel_wrapper.cu:1208 */
+    int64_t live_steps;           /* sum over layers of (layerFirstPassive - beamFirstInside) */
+    int32_t max_radius;           /* largest tile radius over all layers */
+    int32_t reserved[3];
+} rtd_field_info;
+
+typedef struct rtd_handle_s* rtd_handle;
+typedef struct rtd_field_s* rtd_field;
+
+uint32_t rtd_abi_version(void);
+void rtd_default_options(rtd_options* out);
+
+/* Replaces cudaFree(0) context init (kernel_wrapper.cu:388); --gpu_id is finally honoured (config.cpp:13-15). */
+int rtd_create(int device_id, rtd_handle* out);
+int rtd_destroy(rtd_handle h);
+const char* rtd_last_error(rtd_handle h);
+/* Message for a failure that happened before a handle existed (rtd_create). */
+const char* rtd_global_error(void);
+
+int rtd_set_options(rtd_handle h, const rtd_options* opt);
+
+/* LUT upload, replaces the texture set-up (kernel_wrapper.cu:453-537). Arrays are copied. */
+int rtd_set_luts(rtd_handle h, const rtd_luts* luts);
+/* Reads the reference's LUT text layout from a directory (energy_reader.cpp:12-101) and uploads it.
+ * water_cube_test != 0 selects radiation_length_inc_water.txt (energy_reader.cpp:77-93). */
+int rtd_load_luts_dir(rtd_handle h, const char* dir, int water_cube_test);
+
+/* CT upload, replaces cudaMemcpy3D into the 3-D texture (kernel_wrapper.cu:420-451).
+ * hu_plus_1000: [dims[2]][dims[1]][dims[0]] float, host memory. */
+int rtd_set_ct(rtd_handle h, const float* hu_plus_1000, const uint32_t dims[3]);
+/* Same, for a CT already resident on this handle's device (not copied, not owned). */
+int rtd_set_ct_device(rtd_handle h, const float* dev_hu_plus_1000, const uint32_t dims[3]);
+
+/*
+ * The reference-shaped call: for every beam run the whole path and ACCUMULATE into dose_inout
+ * (host memory, [dims[2]][dims[1]][dims[0]]): upload dose (kernel_wrapper.cu:542), beam loop (:601-1312),
+ * download (:1318). timing may be NULL; else it must point to n_beams records.
+ */
+int rtd_compute(rtd_handle h, const rtd_beam* beams, int n_beams, float* dose_inout,
+                const uint32_t dose_dims[3], rtd_timing* timing);
+
+/*
+ * Split form for callers that keep data resident (benchmarks, multi-GPU plans):
+ * rtd_field_create   host geometry + workspace allocation + spot-weight upload for one beam
+ *                    (kernel_wrapper.cu:612-734, 851-852);
+ * rtd_field_compute  launches every kernel of the field on the handle's stream and accumulates into
+ *                    dev_dose (device memory of this handle's device). Asynchronous: no host sync,
+ *                    no allocation, so it can be captured into a hipGraph;
+ * rtd_field_finish   waits for the stream and reports device-side errors (radius overflow).
+ */
+int rtd_field_create(rtd_handle h, const rtd_beam* beam, const uint32_t dose_dims[3], rtd_field* out);
+int rtd_field_compute(rtd_handle h, rtd_field f, float* dev_dose);
+int rtd_field_finish(rtd_handle h, rtd_field f, rtd_timing* timing, rtd_field_info* info);
+int rtd_field_destroy(rtd_handle h, rtd_field f);
+
+/* Device buffers owned by the handle (so a C caller needs no HIP headers). */
+int rtd_device_alloc(rtd_handle h, size_t bytes, void** dev_ptr);
+int rtd_device_free(rtd_handle h, void* dev_ptr);
+int rtd_device_zero(rtd_handle h, void* dev_ptr, size_t bytes);
+int rtd_copy_to_device(rtd_handle h, void* dev_dst, const void* host_src, size_t bytes);
+int rtd_copy_to_host(rtd_handle h, void* host_dst, const void* dev_src, size_t bytes);
+int rtd_sync(rtd_handle h);
+/* The hipStream_t the handle launches on (as void*), for event timing by the caller. */
+void* rtd_stream(rtd_handle h);
+/* Use an externally created hipStream_t (e.g. torch's current stream); NULL restores the handle's own. */
+int rtd_set_stream(rtd_handle h, void* hip_stream);
+
+/*
+ * Introspection for parity tests: copy a named intermediate of the last rtd_field_compute to host.
+ * Names: "density" "wepl" [S][H][W] float; "first_inside" "first_outside" [H][W] int32;
+ * "wepl_min" [S] float; "ray_weights" [L][H][W] float; "idd" "rsigma" [L][S][H][W] float;
+ * "first_passive" [L][H][W] int32; "tile_radius" [L][S][tilesY][tilesX] uint8 (0xFF = not classified);
+ * "eff_radius" [L][34] int32 (batch radius per tile radius); "bev" [S][H+64][W+64] float;
+ * "layer_plan" [L][8] float (energyIdx, scaleFact, peakDepth, entrySigmaX, entrySigmaY, afterLast, 0, 0).
+ * Returns the number of bytes the buffer holds via *bytes_needed when host_out is NULL.
+ */
+int rtd_field_fetch(rtd_handle h, rtd_field f, const char* name, void* host_out, size_t bytes,
+                    size_t* bytes_needed);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* RTD_H */

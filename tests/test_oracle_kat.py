@@ -1,0 +1,182 @@
+"""Known-answer tests of the CPU oracle that follow directly from the reference code:
+water WEPL ramp, IDD/LUT consistency, superposition conservation with the 3-sigma truncation, transform
+round trips, getFanIdx == ToFan::transformPoint (the probe commented out in src/main.cu:220-238)."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from raytracedicom_amd import abi, scenarios
+
+fp = abi.c_float_p
+
+
+def P(a):
+    return a.ctypes.data_as(fp)
+
+
+def f3(*v):
+    return (C.c_float * 3)(*v)
+
+
+def f2(*v):
+    return (C.c_float * 2)(*v)
+
+
+@pytest.fixture(scope="module")
+def c1(orc, synth):
+    """C1: water cube 128^3 @ 2 mm, one field, one layer (BASELINE.json configs[0])."""
+    scn = scenarios.water_cube(synth, n=128, n_layers=1)
+    dose = np.zeros_like(scn.ct)
+    f = orc.run_field(scn, scn.beams[0], dose)
+    assert f.status == 0
+    return scn, f, dose
+
+
+def test_water_cube_probe_values(orc):
+    """SURVEY §8c probe on the reference water cube: ray(0,0) start=(68,68,234), inc=(0,0,-1), stepLen=1, stepVol=1."""
+    L = orc.lib()
+    g2i = scenarios._geometry(256, 1.0, (-128.0, -128.0, -106.0)).as_abi()
+    fan = abi.make_idx_transform((1.0, 1.0, -1.0), (-60.0, -60.0, 128.0))
+    start, inc, sl = f3(0, 0, 0), f3(0, 0, 0), C.c_float()
+    L.orc_tracer_probe(C.byref(fan), f2(math.inf, math.inf), C.byref(g2i), 0, 0, start, inc, C.byref(sl))
+    assert list(start) == [68.0, 68.0, 234.0] and list(inc) == [0.0, 0.0, -1.0] and sl.value == 1.0
+    sv, vw, a, b = C.c_float(), f2(0, 0), C.c_float(), C.c_float()
+    L.orc_fill_probe(C.byref(fan), f2(math.inf, math.inf), C.byref(g2i), C.c_float(100.0), 1, 17, C.byref(sv), vw,
+                     C.byref(a), C.byref(b))
+    assert sv.value == 1.0 and list(vw) == [1.0, 1.0]
+    # air-sigma coefficients (fill_idd_and_sigma_params.cu:74-83) at r0 = 100 mm
+    qa, qb = np.float32(0.00270) / np.float32(100 - 4.5), np.float32(-4.39) / np.float32(100 - 3.86)
+    assert b.value == pytest.approx(float(qa), rel=1e-6)
+    assert a.value == pytest.approx(float(np.float32(2) * qa * np.float32(-1) * np.float32(128) + qb * np.float32(-1)), rel=1e-5)
+
+
+@pytest.mark.parametrize("dist", [(math.inf, math.inf), (2000.0, 2500.0)])
+@pytest.mark.parametrize("deg", [0.0, 90.0, 37.0])
+def test_fan_transform_round_trip_and_transfer_probe(orc, dist, deg):
+    """FromFan o ToFan = id, and TransferParamStructDiv3::getFanIdx == Float3ToFanTransform::transformPoint."""
+    L = orc.lib()
+    g2i = scenarios._geometry(256, 0.5, (-128.0, -128.0, -106.0), deg).as_abi()
+    fan = abi.make_idx_transform((1.0, 1.0, -1.0), (-41.0, -43.0, 128.0))
+    shift = f3(32.0, 32.0, -7.0)
+    zero = f3(0.0, 0.0, 0.0)
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        p = rng.uniform([0, 0, 0], [90, 90, 250]).astype(np.float32)
+        im, back = f3(0, 0, 0), f3(0, 0, 0)
+        L.orc_from_fan_point(C.byref(fan), f2(*dist), C.byref(g2i), f3(*p), im)
+        L.orc_to_fan_point(C.byref(fan), f2(*dist), C.byref(g2i), zero, im, back)
+        np.testing.assert_allclose(list(back), p, atol=2e-3)
+    for (i, j, k) in [(0, 0, 0), (100, 37, 5), (311, 255, 400), (17, 499, 63)]:
+        a, b = f3(0, 0, 0), f3(0, 0, 0)
+        L.orc_transfer_fan_idx(C.byref(fan), f2(*dist), C.byref(g2i), shift, i, j, k, a)
+        L.orc_to_fan_point(C.byref(fan), f2(*dist), C.byref(g2i), shift, f3(float(i), float(j), float(k)), b)
+        np.testing.assert_allclose(list(a), list(b), atol=5e-3)
+
+
+def test_affine_inverse_concat(orc):
+    L = orc.lib()
+    t = scenarios._geometry(256, 0.5, (-128.0, -128.0, -106.0), 37.0).as_abi()
+    inv, ident = abi.RtdAffine(), abi.RtdAffine()
+    L.orc_affine_inverse(C.byref(t), C.byref(inv))
+    L.orc_affine_concat(C.byref(t), C.byref(inv), C.byref(ident))
+    np.testing.assert_allclose(np.array(ident.m).reshape(3, 3), np.eye(3), atol=1e-5)
+    np.testing.assert_allclose(list(ident.v), [0, 0, 0], atol=2e-4)
+
+
+def test_samplers(orc):
+    L = orc.lib()
+    t = abi.f32([1.0, 3.0, 7.0, 4.0])
+    assert L.orc_sample1d(P(t), 4, C.c_float(1.25)) == pytest.approx(0.75 * 3 + 0.25 * 7)
+    assert L.orc_sample1d(P(t), 4, C.c_float(-3.0)) == 1.0 and L.orc_sample1d(P(t), 4, C.c_float(9.0)) == 4.0   # CLAMP
+    m = abi.f32([[0, 1, 2], [10, 11, 12]])
+    assert L.orc_sample2d(P(m), 3, 2, C.c_float(0.5), C.c_float(0.5)) == pytest.approx(5.5)
+    assert L.orc_sample2d(P(m), 3, 2, C.c_float(5.0), C.c_float(7.0)) == 12.0
+    v = abi.f32(np.arange(27).reshape(3, 3, 3))
+    assert L.orc_sample3d(P(v), 3, 3, 3, C.c_float(1.0), C.c_float(1.0), C.c_float(1.0)) == 13.0
+    assert L.orc_sample3d(P(v), 3, 3, 3, C.c_float(0.5), C.c_float(0.0), C.c_float(0.0)) == pytest.approx(0.5)
+    # BORDER: half a voxel outside blends with 0; a full voxel outside is 0
+    assert L.orc_sample3d(P(v), 3, 3, 3, C.c_float(2.5), C.c_float(2.0), C.c_float(2.0)) == pytest.approx(13.0)
+    assert L.orc_sample3d(P(v), 3, 3, 3, C.c_float(3.0), C.c_float(2.0), C.c_float(2.0)) == 0.0
+    assert L.orc_sample3d(P(v), 3, 3, 3, C.c_float(-1.0), C.c_float(2.0), C.c_float(2.0)) == 0.0
+
+
+def test_batch_radii_rule(orc):
+    """kernel_wrapper.cu:966-976 + kernel_wrapper.cuh:443-448: radii are merged downwards until a launch has >= 16 tiles."""
+    L = orc.lib()
+    ctrs = (C.c_int * 34)()
+    eff = (C.c_int * 34)()
+    for r, n in {0: 5, 1: 40, 2: 3, 3: 20, 4: 2, 5: 1}.items():
+        ctrs[r] = n
+    assert L.orc_batch_radii(ctrs, eff) == 5
+    # from the top: 5 (1) + 4 (2) + 3 (20) -> launch<5>; 2 (3) + 1 (40) -> launch<2>; 0 stays 0
+    assert list(eff)[:6] == [0, 2, 2, 5, 5, 5]
+
+
+def test_water_wepl_and_density(c1):
+    scn, f, _ = c1
+    W, H = f.info["ray_dims"][:2]
+    wepl = f.get("wepl").reshape(512, H, W)
+    dens = f.get("density").reshape(512, H, W)
+    k = np.arange(1, 201, dtype=np.float32)
+    np.testing.assert_array_equal(wepl[:200, H // 2, W // 2], k)          # WEPL[k] = (k+1) * stepLen in water
+    np.testing.assert_array_equal(dens[:200], 1.0)
+    assert f.info["beam_first_inside"] == 0
+    assert (f.get("first_inside") == 0).all()
+
+
+def test_idd_matches_lut_difference(c1, orc):
+    """bevIdd[k] * dWEPL * stepVol(k) / w == cIDD(WEPL_k) - cIDD(WEPL_{k-1}) (kernel_wrapper.cu:343-346)."""
+    scn, f, _ = c1
+    L = orc.lib()
+    W, H = f.info["ray_dims"][:2]
+    idd = f.get("idd").reshape(1, 512, H, W)[0]
+    rw = f.get("ray_weights").reshape(H, W)
+    plan = f.get("layer_plan").reshape(-1, 8)[0]
+    y, x = H // 2, W // 2
+    es = scn.luts
+    prev = 0.0
+    for k in range(0, 90):
+        cur = L.orc_sample2d(P(es.ciddMatrix), es.nEnergySamples, es.nEnergies, C.c_float(np.float32(k + 1) * plan[1]),
+                             C.c_float(plan[0]))
+        expect = np.float32(rw[y, x]) * (np.float32(cur) - np.float32(prev)) / np.float32(1.0)
+        assert idd[k, y, x] == pytest.approx(float(expect), rel=1e-6)
+        prev = cur
+
+
+def test_superposition_conserves_dose_up_to_truncation(c1):
+    """Per source voxel the scatter keeps sum_i e[|i|] per axis; erf(3/sqrt2)^2 = 0.9946 at least."""
+    scn, f, _ = c1
+    W, H = f.info["ray_dims"][:2]
+    idd = f.get("idd").reshape(512, H, W).astype(np.float64)
+    bev = f.get("bev").reshape(512, H + 64, W + 64).astype(np.float64)
+    first, last = f.info["beam_first_inside"], f.info["beam_first_calculated_passive"]
+    for k in (first, first + 10, last - 8, last - 1):
+        s_in, s_out = idd[k].sum(), bev[k].sum()
+        assert 0.9945 * s_in <= s_out <= s_in * (1 + 1e-6)
+    assert bev[last:].sum() == 0.0 and bev[:first].sum() == 0.0
+
+
+def test_transfer_identity_geometry(c1):
+    """G000, parallel beam, 1 mm rays onto a 2 mm grid: every second BEV column/slice lands on a dose voxel."""
+    scn, f, dose = c1
+    W, H = f.info["ray_dims"][:2]
+    bev = f.get("bev").reshape(512, H + 64, W + 64)
+    off = f.info["ray_offset"]
+    # dose voxel (x,y,z) world = 2*idx + (-128,-128,-106); ray idx = world - off; step k = 128 - world_z
+    for (x, y, z) in [(64, 64, 80), (50, 70, 100), (40, 40, 90)]:
+        wx, wy, wz = 2 * x - 128, 2 * y - 128, 2 * z - 106
+        i, j, k = int(wx - off[0]), int(wy - off[1]), int(128 - wz)
+        assert dose[z, y, x] == pytest.approx(float(bev[k, j + 32, i + 32]), rel=1e-6)
+    assert dose.max() > 0
+
+
+def test_depth_dose_has_bragg_peak_at_expected_depth(c1):
+    scn, f, dose = c1
+    prof = dose[:, 64, 64]
+    zpk = int(prof.argmax())
+    depth = 128.0 - (2 * zpk - 106)                       # mm from the start plane
+    peak = f.get("layer_plan").reshape(-1, 8)[0][2]
+    assert abs(depth - peak) <= 3.0
+    assert prof[zpk] > 2.5 * prof[zpk + 20]               # entrance plateau well below the peak
