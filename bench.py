@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X dose engine (BASELINE.json metric).
+
+metric   Mvoxels/s of dose deposited: dose-grid voxels x fields / wall time of the plan, inputs (CT, LUTs, spot
+         weights, workspace) already resident in HBM; the dose volume is zeroed inside the timed step.
+workload N=1: C3 = 512^3 synthetic heterogeneous CT, one field, 10x10 spots x 20 energy layers, 512 tracer steps
+         (BASELINE.json configs[2] — the configuration the metric is quoted on).
+         N>1: one field per GPU (gantry angles 360/N apart, same CT replicated), per-rank dose volumes summed into
+         rank 0 with one RCCL reduce inside the timed step (weak scaling: per-GPU work fixed).
+step     = rtd_device_zero(dose) + rtd_field_compute (all kernels of the field) [+ dist.reduce] + sync.
+
+One JSON line on rank 0; `roofline` describes the dominant kernel (kernel superposition) from HIP events recorded
+by the engine on the launch stream during the timed steps; `cpu_baseline` is the CPU oracle timed on this host.
+
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--size 512] [--no-cpu]
+       N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, Chip-level parameters)
+
+
+def algorithmic_bytes(info, dims):
+    """Algorithmic HBM bytes of one field, per stage (SURVEY.md §8d formula; fp32).
+    R rays, S steps, P padded BEV slice, SA = sum over layers of live steps, V_bb = dose voxels in the bounding box.
+    The tracer's CT term uses the ray-grid footprint bound min(N, 8*R*S) (distinct voxels touched <= samples*8)."""
+    W, H, L = info["ray_dims"]
+    R, P = W * H, (W + 64) * (H + 64)
+    S = info["_steps"]
+    SA = info["live_steps"]
+    Z = max(0, info["beam_first_calculated_passive"] - info["beam_first_inside"])
+    bb = [max(0, info["bbox_max"][i] - info["bbox_min"][i] + 1) for i in range(3)]
+    vbb = bb[0] * bb[1] * bb[2]
+    n = dims[0] * dims[1] * dims[2]
+    out = {
+        "tracer": 4 * min(n, info.get("_ct_footprint", n)) + 8 * R * S + 8 * R + 4 * R * S,   # CT + density,WEPL + 2 int maps + min-WEPL read
+        "fill": 16 * R * SA + 4 * R * L + 4 * R * SA,                                       # read rho,WEPL; write idd,1/sigma; weights; tile radius
+        "superposition": 8 * R * SA + 8 * P * SA,                                           # read idd,1/sigma; RMW padded BEV
+        "bev_zero_read": 4 * P * S + 4 * P * Z,
+        "transfer": 8 * vbb,
+    }
+    out["total"] = sum(out.values())
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=512, help="CT edge in voxels (512 = C3/C4, 768 = C5)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    from raytracedicom_amd import abi, engine, luts, scenarios
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the dose engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    # ---- synthetic inputs (same CT on every rank; field r at gantry angle r*360/world) ----
+    n = args.size
+    es = luts.synth_luts()
+    ct_np, voxel = scenarios.hetero_phantom(n)
+    angles = [r * 360.0 / world for r in range(world)]
+    scn = scenarios.hetero_ct(es, n=n, angles=angles, ct=ct_np)
+    beam = scn.beams[rank]
+    n_vox = scn.n_voxels
+
+    eng = engine.Engine(local_rank)
+    opt = abi.default_options()
+    opt.fine_grained_timing = 1
+    eng.set_options(opt)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.set_luts(es)
+    ct_dev = torch.from_numpy(ct_np).to(dev)
+    eng.set_ct_device(ct_dev.data_ptr(), scn.dims)
+    dose = torch.zeros((n, n, n), dtype=torch.float32, device=dev)
+    fld = eng.create_field(beam, scn.dims)
+    torch.cuda.synchronize()
+
+    def step():
+        dose.zero_()
+        fld.compute(dose.data_ptr())
+        if world > 1:
+            dist.reduce(dose, dst=0, op=dist.ReduceOp.SUM)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+        fld.finish()
+    buckets = {}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        t, info = fld.finish()          # stream sync + per-stage hipEvent times of this step
+        for k, v in t.items():
+            buckets[k] = buckets.get(k, 0.0) + float(v)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    ms_per_step = 1000.0 * elapsed / args.steps
+
+    if rank == 0:
+        info["_steps"] = beam.tracerSteps
+        stage_ms = {k: buckets[k] / args.steps for k in buckets if k.endswith("_ms")}
+        alg = algorithmic_bytes(info, scn.dims)
+        ks_ms = stage_ms["superp_ms"]
+        ks_gbs = alg["superposition"] / (ks_ms * 1e-3) / 1e9 if ks_ms > 0 else 0.0
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get("k_superpose", {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "Mvoxels/s dose deposited (%d^3 CT, 1 field per GPU)" % n,
+            "value": round(world * n_vox / elapsed * args.steps / 1e6, 3),
+            "unit": "Mvoxels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C3: %d^3 synthetic heterogeneous CT (HU->density/SP LUTs), %d field(s) one per GPU, "
+                                   "10x10 spots x 20 layers = 2000 spots, 512 tracer steps, 1 mm rays" % (n, world),
+                       "ray_grid": info["ray_dims"], "live_steps": info["live_steps"], "max_radius": info["max_radius"],
+                       "bbox_voxels": int(np.prod([info["bbox_max"][i] - info["bbox_min"][i] + 1 for i in range(3)])),
+                       "reduce": "rccl reduce(sum) to rank 0" if world > 1 else "none"},
+            "ms_plan": round(ms_per_step, 4),
+            "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+            "algorithmic_bytes": alg,
+            "path_gbs": round(alg["total"] / (stage_ms["total_ms"] * 1e-3) / 1e9, 2),
+            "roofline": {"kernel": "k_superpose", "bound": "hbm", "achieved": round(ks_gbs, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(ks_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "avg_launch_ms": round(ks_ms, 4), "algorithmic_bytes_per_launch": alg["superposition"],
+                         "note": "superposition is LDS/VALU-bound, not HBM-bound (SURVEY.md §7); HBM fraction reported as the contract asks"},
+        }
+        if not args.no_cpu and world == 1:
+            from oracle import oracle
+            ncpu = args.cpu_threads or min(16, os.cpu_count() or 1)
+            oracle.set_threads(ncpu)
+            cpu_dose = np.zeros_like(scn.ct)
+            c0 = time.perf_counter()
+            of = oracle.run_field(scn, beam, cpu_dose, keep_layers=False)
+            cpu_s = time.perf_counter() - c0
+            host = dose.cpu().numpy()
+            rate, n_eval, gmax = oracle.gamma_pass_rate(cpu_dose, host, scn.spacing)
+            thr = cpu_dose > 0.1 * cpu_dose.max()
+            max_rel = float((np.abs(host - cpu_dose)[thr] / cpu_dose[thr]).max())
+            result["cpu_baseline"] = {"value": round(n_vox / cpu_s / 1e6, 3), "unit": "Mvoxels/s", "cores": ncpu, "kind": "port",
+                                      "sample": "the full N=1 workload (one C3 field), CPU oracle with %d OpenMP threads, %.1f s wall" % (ncpu, cpu_s)}
+            result["parity"] = {"gamma_1pct_1mm_pass": rate, "gamma_voxels": n_eval, "gamma_max": round(gmax, 4),
+                                "max_rel_diff_above_10pct": max_rel}
+            of.close()
+        print(json.dumps(result))
+    fld.destroy()
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -461,8 +461,9 @@ static void stage_conv2d(const float* in, float* interm, float* out, const f2* s
             float sigmaEff = sigmas[z].x / pixelSpX;
             float rSigmaEff = (1.0f / sqrtf(2.0f)) / sigmaEff;
             int cur = f2i_sat(ceilf(((float)outIdxX - (convCut * sigmaEff + 0.5f) - inOutOffsetX) / inOutDeltaX));
+            if (cur < 0) cur = 0;   /* spots left of the map contribute nothing; bounds the loop, same result */
             float dist = (float)cur * inOutDeltaX + inOutOffsetX - (float)outIdxX;
-            while (dist < (convCut * sigmaEff + 0.5f)) {
+            while (dist < (convCut * sigmaEff + 0.5f) && cur < inW) {
                 if (cur >= 0 && cur < inW)
                     res += 0.5f * (erff((dist + 0.5f) * rSigmaEff) - erff((dist - 0.5f) * rSigmaEff))
                            * in[(size_t)z * inW * inH + (size_t)idxY * inW + cur];
@@ -477,8 +478,9 @@ static void stage_conv2d(const float* in, float* interm, float* out, const f2* s
             float sigmaEff = sigmas[z].y / pixelSpY;
             float rSigmaEff = (1.0f / sqrtf(2.0f)) / sigmaEff;
             int cur = f2i_sat(ceilf(((float)outIdxY - (convCut * sigmaEff + 0.5f) - inOutOffsetY) / inOutDeltaY));
+            if (cur < 0) cur = 0;
             float dist = (float)cur * inOutDeltaY + inOutOffsetY - (float)outIdxY;
-            while (dist < (convCut * sigmaEff + 0.5f)) {
+            while (dist < (convCut * sigmaEff + 0.5f) && cur < inH) {
                 if (cur >= 0 && cur < inH)
                     res += 0.5f * (erff((dist + 0.5f) * rSigmaEff) - erff((dist - 0.5f) * rSigmaEff))
                            * interm[(size_t)z * outW * inH + (size_t)cur * outW + idxX];
@@ -758,7 +760,7 @@ int orc_field_run(const rtd_luts* l, const float* ct, const uint32_t ctDims[3], 
     f->firstOutside = (int*)malloc(sizeof(int) * R);
     f->weplMin = (float*)malloc(sizeof(float) * S);
     f->rayWeights = (float*)malloc(sizeof(float) * R * L);
-    f->firstPassive = (int*)malloc(sizeof(int) * R * L);
+    f->firstPassive = (int*)calloc(R * L, sizeof(int));
     const size_t layerElems = R * (size_t)S;
     const size_t nKeep = keepLayers ? (size_t)L : 1;
     f->idd = (float*)calloc(layerElems * nKeep, sizeof(float));

@@ -1,0 +1,585 @@
+// rtd_engine.hip — host side of the MI355X dose engine and its C ABI (include/rtd.h).
+//
+// Replaces the orchestration of cudaWrapperProtons (reference src/kernel_wrapper.cu:381-1369):
+//   * one handle = one device + one stream + resident CT and LUTs (the reference re-uploads per call, :418-537);
+//   * one field object = host geometry of a beam (:612-663) + a workspace allocated once (the reference does
+//     ~20 cudaMalloc/cudaFree per beam, :685-734, :1265-1281);
+//   * rtd_field_compute = a fixed sequence of asynchronous launches; every scalar the reference reads back
+//     to the host between kernels (:783,787,790,954,963) stays in device memory (k_plan, k_ks_plan).
+// There is no CPU fallback: without a HIP device every entry point fails with RTD_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/rtd.h"
+#include "rtd_geometry.hpp"
+#include "rtd_kernels.hpp"
+
+using namespace rtd;
+
+namespace {
+
+thread_local std::string g_globalError;
+
+struct rtd_handle_impl {
+    int device = 0;
+    hipStream_t ownStream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string error;
+    rtd_options opt{};
+    // LUTs
+    bool haveLuts = false;
+    std::vector<float> energiesPerU, peakDepths, scaleFacts;
+    float densityScale = 0, spScale = 0, rrlScale = 0;
+    float* dLutBlock = nullptr;   // one allocation: cidd | density | sp | rrl
+    LutView lut{};
+    // CT
+    const float* dCt = nullptr;
+    float* dCtOwned = nullptr;
+    uint32_t ctDims[3] = {0, 0, 0};
+};
+
+struct rtd_field_impl {
+    FieldConst fc{};
+    TracerParams tracer{};
+    FillGeom fillGeom{};
+    FromFan rayIdxToDoseIdx{};
+    TransferParams transfer0{};
+    uint32_t doseDims[3] = {0, 0, 0};
+    size_t R = 0;
+    // device workspace
+    float *dSpotWeights = nullptr, *dConvInterm = nullptr, *dRayWeights = nullptr;
+    float *dDensity = nullptr, *dWepl = nullptr, *dIdd = nullptr, *dRSigma = nullptr, *dBev = nullptr;
+    int *dFirstInside = nullptr, *dFirstOutside = nullptr, *dFirstPassive = nullptr, *dWeplMin = nullptr;
+    unsigned char* dTileRad = nullptr;
+    unsigned int* dWorkList = nullptr;
+    LayerPlan* dLayers = nullptr;
+    FieldState* dState = nullptr;
+    std::vector<LayerPlan> hLayers;
+    hipEvent_t ev[8] = {};
+    bool computed = false;
+    int superpBlocks = 0;
+};
+
+#define RTD_HIP(h, call)                                                                         \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            char buf_[512];                                                                      \
+            snprintf(buf_, sizeof buf_, "HIP error: %s %s %d", hipGetErrorString(e_), __FILE__, __LINE__); \
+            (h)->error = buf_;                                                                   \
+            return RTD_ERR_HIP;                                                                  \
+        }                                                                                        \
+    } while (0)
+
+int fail(rtd_handle_impl* h, int code, const std::string& msg) { h->error = msg; return code; }
+
+Affine toAffine(const rtd_affine& a) {
+    Affine r;
+    r.m.r0 = v3(a.m[0], a.m[1], a.m[2]); r.m.r1 = v3(a.m[3], a.m[4], a.m[5]); r.m.r2 = v3(a.m[6], a.m[7], a.m[8]);
+    r.v = v3(a.v[0], a.v[1], a.v[2]);
+    return r;
+}
+IdxTransform toIdx(const rtd_idx_transform& t) {
+    IdxTransform r; r.delta = v3(t.delta[0], t.delta[1], t.delta[2]); r.offset = v3(t.offset[0], t.offset[1], t.offset[2]);
+    return r;
+}
+
+template <typename T>
+int devAlloc(rtd_handle_impl* h, T** p, size_t n) {
+    RTD_HIP(h, hipMalloc((void**)p, n * sizeof(T)));
+    return RTD_OK;
+}
+
+// LUT text layout of the reference (energy_reader.cpp:12-101): "N scale" header then N values.
+bool readTokens(const std::string& path, std::vector<double>& out) {
+    std::ifstream f(path.c_str());
+    if (!f) return false;
+    double v;
+    while (f >> v) out.push_back(v);
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t rtd_abi_version(void) { return RTD_ABI_VERSION; }
+
+void rtd_default_options(rtd_options* o) {   // CMakeLists.txt:36-79
+    std::memset(o, 0, sizeof *o);
+    o->dose_to_water = 1; o->nozzle = 1;
+    o->bp_depth_cutoff = 1.05f; o->conv_sigma_cutoff = 3.0f; o->ks_sigma_cutoff = 3.0f; o->ray_weight_cutoff = 1.0f;
+    o->fine_grained_timing = 0;
+}
+
+const char* rtd_global_error(void) { return g_globalError.c_str(); }
+
+int rtd_create(int device_id, rtd_handle* out) {
+    if (!out) return RTD_ERR_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_globalError = "no HIP device available: the dose engine has no CPU fallback";
+        return RTD_ERR_NO_DEVICE;
+    }
+    if (device_id < 0 || device_id >= n) { g_globalError = "device id out of range"; return RTD_ERR_INVALID_ARG; }
+    auto* h = new rtd_handle_impl();
+    h->device = device_id;
+    rtd_default_options(&h->opt);
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&h->ownStream, hipStreamNonBlocking) != hipSuccess) {
+        g_globalError = "hipSetDevice / hipStreamCreate failed";
+        delete h;
+        return RTD_ERR_HIP;
+    }
+    h->stream = h->ownStream;
+    *out = reinterpret_cast<rtd_handle>(h);
+    return RTD_OK;
+}
+
+int rtd_destroy(rtd_handle hh) {
+    auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
+    if (!h) return RTD_ERR_INVALID_ARG;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    if (h->dLutBlock) (void)hipFree(h->dLutBlock);
+    if (h->dCtOwned) (void)hipFree(h->dCtOwned);
+    if (h->ownStream) (void)hipStreamDestroy(h->ownStream);
+    delete h;
+    return RTD_OK;
+}
+
+const char* rtd_last_error(rtd_handle hh) {
+    auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
+    return h ? h->error.c_str() : "null handle";
+}
+
+int rtd_set_options(rtd_handle hh, const rtd_options* opt) {
+    auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
+    if (!h || !opt) return RTD_ERR_INVALID_ARG;
+    h->opt = *opt;
+    return RTD_OK;
+}
+
+void* rtd_stream(rtd_handle hh) {
+    auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
+    return h ? (void*)h->stream : nullptr;
+}
+
+int rtd_set_stream(rtd_handle hh, void* s) {
+    auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
+    if (!h) return RTD_ERR_INVALID_ARG;
+    h->stream = s ? (hipStream_t)s : h->ownStream;
+    return RTD_OK;
+}
+
+int rtd_sync(rtd_handle hh) {
+    auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
+    if (!h) return RTD_ERR_INVALID_ARG;
+    RTD_HIP(h, hipStreamSynchronize(h->stream));
+    return RTD_OK;
+}
+
+int rtd_device_alloc(rtd_handle hh, size_t bytes, void** p) {
+    auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
+    if (!h || !p) return RTD_ERR_INVALID_ARG;
+    RTD_HIP(h, hipSetDevice(h->device));
+    RTD_HIP(h, hipMalloc(p, bytes));
+    return RTD_OK;
+}
+int rtd_device_free(rtd_handle hh, void* p) {
+    auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
+    if (!h) return RTD_ERR_INVALID_ARG;
+    RTD_HIP(h, hipFree(p));
+    return RTD_OK;
+}
+int rtd_device_zero(rtd_handle hh, void* p, size_t bytes) {
+    auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
+    if (!h) return RTD_ERR_INVALID_ARG;
+    RTD_HIP(h, hipMemsetAsync(p, 0, bytes, h->stream));
+    return RTD_OK;
+}
+int rtd_copy_to_device(rtd_handle hh, void* d, const void* s, size_t bytes) {
+    auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
+    if (!h) return RTD_ERR_INVALID_ARG;
+    RTD_HIP(h, hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, h->stream));
+    RTD_HIP(h, hipStreamSynchronize(h->stream));
+    return RTD_OK;
+}
+int rtd_copy_to_host(rtd_handle hh, void* d, const void* s, size_t bytes) {
+    auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
+    if (!h) return RTD_ERR_INVALID_ARG;
+    RTD_HIP(h, hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToHost, h->stream));
+    RTD_HIP(h, hipStreamSynchronize(h->stream));
+    return RTD_OK;
+}
+
+int rtd_set_luts(rtd_handle hh, const rtd_luts* l) {   // kernel_wrapper.cu:453-537
+    auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
+    if (!h || !l) return RTD_ERR_INVALID_ARG;
+    if (l->n_energies <= 0 || l->n_energy_samples <= 0 || l->n_density_samples <= 0 || l->n_sp_samples <= 0 ||
+        l->n_rrl_samples <= 0 || !l->energies_per_u || !l->peak_depths || !l->scale_facts || !l->cidd_matrix ||
+        !l->density_vector || !l->sp_vector || !l->rrl_vector)
+        return fail(h, RTD_ERR_INVALID_ARG, "rtd_set_luts: empty or null table");
+    RTD_HIP(h, hipSetDevice(h->device));
+    const size_t nC = (size_t)l->n_energies * l->n_energy_samples, nD = l->n_density_samples, nS = l->n_sp_samples, nR = l->n_rrl_samples;
+    if (h->dLutBlock) { RTD_HIP(h, hipStreamSynchronize(h->stream)); RTD_HIP(h, hipFree(h->dLutBlock)); h->dLutBlock = nullptr; }
+    RTD_HIP(h, hipMalloc((void**)&h->dLutBlock, (nC + nD + nS + nR) * sizeof(float)));
+    float* p = h->dLutBlock;
+    RTD_HIP(h, hipMemcpy(p, l->cidd_matrix, nC * 4, hipMemcpyHostToDevice)); h->lut.cidd = p; p += nC;
+    RTD_HIP(h, hipMemcpy(p, l->density_vector, nD * 4, hipMemcpyHostToDevice)); h->lut.density = p; p += nD;
+    RTD_HIP(h, hipMemcpy(p, l->sp_vector, nS * 4, hipMemcpyHostToDevice)); h->lut.sp = p; p += nS;
+    RTD_HIP(h, hipMemcpy(p, l->rrl_vector, nR * 4, hipMemcpyHostToDevice)); h->lut.rrl = p;
+    h->lut.nSamples = l->n_energy_samples; h->lut.nEnergies = l->n_energies;
+    h->lut.nDensity = (int)nD; h->lut.nSp = (int)nS; h->lut.nRrl = (int)nR;
+    h->energiesPerU.assign(l->energies_per_u, l->energies_per_u + l->n_energies);
+    h->peakDepths.assign(l->peak_depths, l->peak_depths + l->n_energies);
+    h->scaleFacts.assign(l->scale_facts, l->scale_facts + l->n_energies);
+    h->densityScale = l->density_scale_fact; h->spScale = l->sp_scale_fact; h->rrlScale = l->rrl_scale_fact;
+    h->haveLuts = true;
+    return RTD_OK;
+}
+
+int rtd_load_luts_dir(rtd_handle hh, const char* dir, int water_cube_test) {   // energy_reader.cpp:12-101
+    auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
+    if (!h || !dir) return RTD_ERR_INVALID_ARG;
+    std::string d(dir);
+    if (!d.empty() && d.back() != '/') d += '/';
+    std::vector<double> t;
+    if (!readTokens(d + "proton_cumul_ddd_data.txt", t) || t.size() < 2)
+        return fail(h, RTD_ERR_IO, "Failed to open " + d + "proton_cumul_ddd_data.txt");
+    const int nS = (int)t[0], nE = (int)t[1];
+    if (nS <= 0 || nE <= 0 || t.size() < 2 + 3 * (size_t)nE + (size_t)nS * nE)
+        return fail(h, RTD_ERR_IO, "Truncated " + d + "proton_cumul_ddd_data.txt");
+    std::vector<float> e(nE), p(nE), s(nE), m((size_t)nS * nE);
+    size_t o = 2;
+    for (int i = 0; i < nE; ++i) e[i] = (float)t[o++];
+    for (int i = 0; i < nE; ++i) p[i] = (float)t[o++];
+    for (int i = 0; i < nE; ++i) s[i] = (float)t[o++];
+    for (size_t i = 0; i < m.size(); ++i) m[i] = (float)t[o++];
+    auto one = [&](const std::string& name, int& n, float& scale, std::vector<float>& v) -> bool {
+        std::vector<double> tt;
+        if (!readTokens(d + name, tt) || tt.size() < 2) return false;
+        n = (int)tt[0]; scale = (float)tt[1];
+        if (n <= 0 || tt.size() < 2 + (size_t)n) return false;
+        v.resize(n);
+        for (int i = 0; i < n; ++i) v[i] = (float)tt[2 + i];
+        return true;
+    };
+    rtd_luts l{};
+    std::vector<float> dv, sv, rv;
+    if (!one("density_Schneider2000_adj.txt", l.n_density_samples, l.density_scale_fact, dv))
+        return fail(h, RTD_ERR_IO, "Failed to open " + d + "density_Schneider2000_adj.txt");
+    if (!one("HU_to_SP_H&N_adj.txt", l.n_sp_samples, l.sp_scale_fact, sv))
+        return fail(h, RTD_ERR_IO, "Failed to open " + d + "HU_to_SP_H&N_adj.txt");
+    const char* rname = water_cube_test ? "radiation_length_inc_water.txt" : "radiation_length.txt";
+    if (!one(rname, l.n_rrl_samples, l.rrl_scale_fact, rv))
+        return fail(h, RTD_ERR_IO, "Failed to open " + d + rname);
+    l.n_energy_samples = nS; l.n_energies = nE;
+    l.energies_per_u = e.data(); l.peak_depths = p.data(); l.scale_facts = s.data(); l.cidd_matrix = m.data();
+    l.density_vector = dv.data(); l.sp_vector = sv.data(); l.rrl_vector = rv.data();
+    return rtd_set_luts(hh, &l);
+}
+
+int rtd_set_ct_device(rtd_handle hh, const float* dev, const uint32_t dims[3]) {
+    auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
+    if (!h || !dev || !dims || !dims[0] || !dims[1] || !dims[2]) return RTD_ERR_INVALID_ARG;
+    if (h->dCtOwned) { RTD_HIP(h, hipStreamSynchronize(h->stream)); RTD_HIP(h, hipFree(h->dCtOwned)); h->dCtOwned = nullptr; }
+    h->dCt = dev;
+    std::memcpy(h->ctDims, dims, sizeof h->ctDims);
+    return RTD_OK;
+}
+
+int rtd_set_ct(rtd_handle hh, const float* host, const uint32_t dims[3]) {   // kernel_wrapper.cu:420-451
+    auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
+    if (!h || !host || !dims || !dims[0] || !dims[1] || !dims[2]) return RTD_ERR_INVALID_ARG;
+    RTD_HIP(h, hipSetDevice(h->device));
+    const size_t n = (size_t)dims[0] * dims[1] * dims[2];
+    if (h->dCtOwned) { RTD_HIP(h, hipStreamSynchronize(h->stream)); RTD_HIP(h, hipFree(h->dCtOwned)); h->dCtOwned = nullptr; }
+    RTD_HIP(h, hipMalloc((void**)&h->dCtOwned, n * sizeof(float)));
+    RTD_HIP(h, hipMemcpy(h->dCtOwned, host, n * sizeof(float), hipMemcpyHostToDevice));
+    h->dCt = h->dCtOwned;
+    std::memcpy(h->ctDims, dims, sizeof h->ctDims);
+    return RTD_OK;
+}
+
+int rtd_field_destroy(rtd_handle hh, rtd_field ff) {
+    auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
+    auto* f = reinterpret_cast<rtd_field_impl*>(ff);
+    if (!h || !f) return RTD_ERR_INVALID_ARG;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    void* ptrs[] = { f->dSpotWeights, f->dConvInterm, f->dRayWeights, f->dDensity, f->dWepl, f->dIdd, f->dRSigma, f->dBev,
+                     f->dFirstInside, f->dFirstOutside, f->dFirstPassive, f->dWeplMin, f->dTileRad, f->dWorkList,
+                     f->dLayers, f->dState };
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto& e : f->ev) if (e) (void)hipEventDestroy(e);
+    delete f;
+    return RTD_OK;
+}
+
+// Host geometry of one beam (kernel_wrapper.cu:612-663, 829-838) + workspace allocation + spot-weight upload (:851).
+int rtd_field_create(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dims[3], rtd_field* out) {
+    auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
+    if (!h || !b || !dose_dims || !out) return RTD_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!h->haveLuts || !h->dCt) return fail(h, RTD_ERR_NOT_READY, "rtd_field_create: set LUTs and CT first");
+    if (b->n_layers == 0) return fail(h, RTD_ERR_INVALID_ARG, "Empty list");   // findMax on an empty vector, vector_find.h:24
+    if (!b->spot_weights || !b->energies || !b->spot_sigmas || b->spot_nx == 0 || b->spot_ny == 0 || b->tracer_steps == 0)
+        return fail(h, RTD_ERR_INVALID_ARG, "rtd_field_create: null or empty beam field");
+    if (!(b->ray_spacing[0] > 0.0f) || !(b->ray_spacing[1] > 0.0f) || !(b->spot_idx_to_gantry.delta[0] > 0.0f) ||
+        !(b->spot_idx_to_gantry.delta[1] > 0.0f) || b->spot_idx_to_gantry.delta[2] == 0.0f)
+        return fail(h, RTD_ERR_INVALID_ARG, "rtd_field_create: ray spacing and spot pitch must be positive, step length non-zero");
+    RTD_HIP(h, hipSetDevice(h->device));
+    const rtd_options& opt = h->opt;
+    const int L = (int)b->n_layers, S = (int)b->tracer_steps;
+
+    float maxSx = b->spot_sigmas[0], maxSy = b->spot_sigmas[1];
+    for (int i = 1; i < L; ++i) { maxSx = std::max(maxSx, b->spot_sigmas[2 * i]); maxSy = std::max(maxSy, b->spot_sigmas[2 * i + 1]); }
+    const IdxTransform sitg = toIdx(b->spot_idx_to_gantry);
+    const Vec3 res = v3(b->ray_spacing[0], b->ray_spacing[1], sitg.delta.z);                                  // :623
+    const float cc = opt.conv_sigma_cutoff;
+    const int lSteps = (int)std::ceil((sitg.offset.x - (cc * maxSx + 0.5f * res.x)) / res.x);                  // :650-653
+    const int bSteps = (int)std::ceil((sitg.offset.y - (cc * maxSy + 0.5f * res.y)) / res.y);
+    const int rSteps = (int)std::floor(((float)(b->spot_nx - 1) * sitg.delta.x + sitg.offset.x + (cc * maxSx + 0.5f * res.x)) / res.x);
+    const int tSteps = (int)std::floor(((float)(b->spot_ny - 1) * sitg.delta.y + sitg.offset.y + (cc * maxSy + 0.5f * res.y)) / res.y);
+    const Vec3 off = v3(res.x * (float)lSteps, res.y * (float)bSteps, sitg.offset.z);                          // :654
+    const int W = roundTo(rSteps - lSteps + 1, kSuperpTileX), H = roundTo(tSteps - bSteps + 1, kSuperpTileY);   // :659
+    if (W <= 0 || H <= 0) return fail(h, RTD_ERR_INVALID_ARG, "rtd_field_create: empty ray grid");
+    const int tilesX = W / kSuperpTileX, tilesY = H / kSuperpTileY;
+    if (L > kMaxLayers || S > kMaxSteps || tilesX * tilesY > kMaxTiles)
+        return fail(h, RTD_ERR_INVALID_ARG, "rtd_field_create: more than 256 layers, 4096 steps or 4096 ray tiles");
+
+    auto* f = new rtd_field_impl();
+    FieldConst& fc = f->fc;
+    fc.W = W; fc.H = H; fc.L = L; fc.S = S; fc.bevW = W + 2 * kMaxSuperpR; fc.bevH = H + 2 * kMaxSuperpR;
+    fc.tilesX = tilesX; fc.tilesY = tilesY;
+    fc.rayRes[0] = res.x; fc.rayRes[1] = res.y; fc.rayRes[2] = res.z;
+    fc.rayOffset[0] = off.x; fc.rayOffset[1] = off.y; fc.rayOffset[2] = off.z;
+    fc.sourceDist[0] = b->source_dist[0]; fc.sourceDist[1] = b->source_dist[1];
+    fc.spotNx = (int)b->spot_nx; fc.spotNy = (int)b->spot_ny;
+    fc.spotDelta[0] = sitg.delta.x; fc.spotDelta[1] = sitg.delta.y; fc.spotDelta[2] = sitg.delta.z;
+    fc.spotOffset[0] = sitg.offset.x; fc.spotOffset[1] = sitg.offset.y; fc.spotOffset[2] = sitg.offset.z;
+    fc.bpDepthCutoff = opt.bp_depth_cutoff; fc.convSigmaCutoff = opt.conv_sigma_cutoff;
+    fc.ksSigmaCutoff = opt.ks_sigma_cutoff; fc.rayWeightCutoff = opt.ray_weight_cutoff;
+    fc.doseToWater = opt.dose_to_water; fc.nozzle = opt.nozzle;
+    std::memcpy(f->doseDims, dose_dims, sizeof f->doseDims);
+    f->R = (size_t)W * H;
+
+    IdxTransform primRayIdxToGantry; primRayIdxToGantry.delta = res; primRayIdxToGantry.offset = off;          // :656
+    FromFan rayIdxToImIdx; rayIdxToImIdx.fitf = primRayIdxToGantry; rayIdxToImIdx.gtii = toAffine(b->gantry_to_im_idx);
+    rayIdxToImIdx.dist.x = b->source_dist[0]; rayIdxToImIdx.dist.y = b->source_dist[1];                        // :657
+    f->tracer = makeTracerParams(h->densityScale, h->spScale, (unsigned int)S, rayIdxToImIdx);                 // :766
+    f->fillGeom = makeFillGeom(h->rrlScale, rayIdxToImIdx);                                                    // :925
+    f->rayIdxToDoseIdx = rayIdxToImIdx; f->rayIdxToDoseIdx.gtii = toAffine(b->gantry_to_dose_idx);             // :1185
+    f->transfer0 = makeTransferParams(invertAndShift(f->rayIdxToDoseIdx, v3((float)kMaxSuperpR, (float)kMaxSuperpR, 0.0f)));  // :1213 (z shift on device)
+
+    // per-layer beam-model tables (:792-794, :829-838)
+    const int nE = (int)h->energiesPerU.size();
+    float maxEnergy = b->energies[0];
+    for (int i = 1; i < L; ++i) maxEnergy = std::max(maxEnergy, b->energies[i]);
+    fc.maxPeakDepth = vectorInterpolate(h->peakDepths.data(), nE, findDecimalOrdered(h->energiesPerU.data(), nE, maxEnergy));
+    f->hLayers.resize(L);
+    for (int l = 0; l < L; ++l) {
+        LayerPlan& p = f->hLayers[l];
+        std::memset(&p, 0, sizeof p);
+        p.energyIdx = findDecimalOrdered(h->energiesPerU.data(), nE, b->energies[l]);
+        p.energyScaleFact = vectorInterpolate(h->scaleFacts.data(), nE, p.energyIdx);
+        p.peakDepth = vectorInterpolate(h->peakDepths.data(), nE, p.energyIdx);
+        p.spotSigmaX = b->spot_sigmas[2 * l]; p.spotSigmaY = b->spot_sigmas[2 * l + 1];
+        Vec2 c = sigmaSqAirCoefs(p.peakDepth, opt.nozzle);
+        p.airCoefA = c.x; p.airCoefB = c.y;
+        const float relStepLenSq = 1.0f;                                                                       // fill_idd_and_sigma_params.cu:28-40
+        p.sigmaSqAirQuad = c.x * relStepLenSq * res.z * res.z;
+        p.sigmaSqAirLin = 2.0f * c.x * relStepLenSq * res.z * off.z + c.y * res.z;
+        for (int i = 0; i < kMaxSuperpR + 2; ++i) p.effRad[i] = i;
+    }
+
+    // workspace (the reference's per-beam cudaMallocs, :685-734, :804-808)
+    const size_t R = f->R, P = (size_t)fc.bevW * fc.bevH;
+    const size_t nSpot = (size_t)b->spot_nx * b->spot_ny * L;
+    const size_t workCap = (size_t)L * S * tilesX * tilesY;
+    fc.workCapacity = (unsigned int)std::min<size_t>(workCap, 0xFFFFFFFFull);
+    int st = RTD_OK;
+    auto A = [&](auto** p, size_t n) { if (st == RTD_OK) st = devAlloc(h, p, n); };
+    A(&f->dSpotWeights, nSpot); A(&f->dConvInterm, (size_t)W * b->spot_ny * L); A(&f->dRayWeights, R * L);
+    A(&f->dDensity, R * S); A(&f->dWepl, R * S); A(&f->dIdd, R * S * L); A(&f->dRSigma, R * S * L); A(&f->dBev, P * S);
+    A(&f->dFirstInside, R); A(&f->dFirstOutside, R); A(&f->dFirstPassive, R * L); A(&f->dWeplMin, (size_t)S);
+    A(&f->dTileRad, (size_t)L * S * tilesX * tilesY); A(&f->dWorkList, workCap); A(&f->dLayers, (size_t)L); A(&f->dState, (size_t)1);
+    if (st != RTD_OK) { rtd_field_destroy(hh, reinterpret_cast<rtd_field>(f)); return st; }
+    hipError_t e = hipMemcpy(f->dSpotWeights, b->spot_weights, nSpot * sizeof(float), hipMemcpyHostToDevice);   // :851
+    if (e == hipSuccess) e = hipMemcpy(f->dLayers, f->hLayers.data(), (size_t)L * sizeof(LayerPlan), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(f->dState, 0, sizeof(FieldState));
+    for (auto& ev : f->ev) if (e == hipSuccess) e = hipEventCreate(&ev);
+    if (e != hipSuccess) { h->error = std::string("HIP error: ") + hipGetErrorString(e); rtd_field_destroy(hh, reinterpret_cast<rtd_field>(f)); return RTD_ERR_HIP; }
+    int nCu = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) nCu = prop.multiProcessorCount;
+    f->superpBlocks = nCu * 2;
+    *out = reinterpret_cast<rtd_field>(f);
+    return RTD_OK;
+}
+
+// The beam loop body as launches only (kernel_wrapper.cu:766-1218). Asynchronous on the handle's stream.
+int rtd_field_compute(rtd_handle hh, rtd_field ff, float* dev_dose) {
+    auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
+    auto* f = reinterpret_cast<rtd_field_impl*>(ff);
+    if (!h || !f || !dev_dose) return RTD_ERR_INVALID_ARG;
+    if (!h->dCt || !h->haveLuts) return fail(h, RTD_ERR_NOT_READY, "rtd_field_compute: set LUTs and CT first");
+    const FieldConst& fc = f->fc;
+    hipStream_t s = h->stream;
+    const bool timing = h->opt.fine_grained_timing != 0;
+    const dim3 blk(kSuperpTileX, kSuperpTileY);
+    const dim3 rayGrid(fc.W / kSuperpTileX, fc.H / kSuperpTileY);
+    const size_t P = (size_t)fc.bevW * fc.bevH;
+
+    RTD_HIP(h, hipEventRecord(f->ev[0], s));
+    k_reset<<<4, 256, 0, s>>>(f->dState, f->dLayers, fc.L, f->dWeplMin, fc.S);
+    const size_t lutLds = (size_t)(h->lut.nDensity + h->lut.nSp) * sizeof(float);
+    k_trace<<<rayGrid, blk, lutLds, s>>>(h->dCt, (int)h->ctDims[0], (int)h->ctDims[1], (int)h->ctDims[2], h->lut, f->tracer,
+                                         fc.W, fc.H, f->dDensity, f->dWepl, f->dFirstInside, f->dFirstOutside, f->dWeplMin, f->dState);
+    if (timing) RTD_HIP(h, hipEventRecord(f->ev[1], s));
+    k_plan<<<1, 64, 0, s>>>(f->dState, f->dLayers, f->dWeplMin, fc);
+    RTD_HIP(h, hipMemsetAsync(f->dBev, 0, P * fc.S * sizeof(float), s));                       // fillDevMem, :824-827
+    RTD_HIP(h, hipMemsetAsync(f->dTileRad, kNoRadius, (size_t)fc.L * fc.S * fc.tilesX * fc.tilesY, s));
+    k_conv_x<<<dim3(fc.W / 32, (fc.spotNy + 7) / 8, fc.L), blk, 0, s>>>(f->dSpotWeights, f->dConvInterm, f->dLayers, f->dState, fc);
+    k_conv_y<<<dim3(fc.W / 32, fc.H / 8, fc.L), blk, 0, s>>>(f->dConvInterm, f->dRayWeights, f->dLayers, f->dState, fc);
+    if (timing) RTD_HIP(h, hipEventRecord(f->ev[2], s));
+    k_fill<<<dim3(rayGrid.x, rayGrid.y, fc.L), blk, 0, s>>>(f->dDensity, f->dWepl, f->dIdd, f->dRSigma, f->dRayWeights, f->dFirstInside,
+                                                            f->dFirstOutside, f->dFirstPassive, f->dTileRad, f->dWorkList, f->dLayers,
+                                                            f->dState, h->lut, f->fillGeom, fc);
+    if (timing) RTD_HIP(h, hipEventRecord(f->ev[3], s));
+    k_ks_plan<<<1, 64, 0, s>>>(f->dState, f->dLayers, fc, f->rayIdxToDoseIdx, f->transfer0, (int)f->doseDims[0], (int)f->doseDims[1],
+                               (int)f->doseDims[2]);
+    if (timing) RTD_HIP(h, hipEventRecord(f->ev[4], s));
+    k_superpose<<<f->superpBlocks, blk, 0, s>>>(f->dIdd, f->dRSigma, f->dBev, f->dTileRad, f->dWorkList, f->dLayers, f->dState, fc);
+    if (timing) RTD_HIP(h, hipEventRecord(f->ev[5], s));
+    k_transfer<<<dim3((f->doseDims[0] + 31) / 32, (f->doseDims[1] + 7) / 8), blk, 0, s>>>(dev_dose, (int)f->doseDims[0], (int)f->doseDims[1],
+                                                                                          (int)f->doseDims[2], f->dBev, f->dState, fc);
+    RTD_HIP(h, hipEventRecord(f->ev[6], s));
+    RTD_HIP(h, hipGetLastError());
+    f->computed = true;
+    return RTD_OK;
+}
+
+int rtd_field_finish(rtd_handle hh, rtd_field ff, rtd_timing* timing, rtd_field_info* info) {
+    auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
+    auto* f = reinterpret_cast<rtd_field_impl*>(ff);
+    if (!h || !f) return RTD_ERR_INVALID_ARG;
+    RTD_HIP(h, hipStreamSynchronize(h->stream));
+    if (!f->computed) return fail(h, RTD_ERR_NOT_READY, "rtd_field_finish: field not computed");
+    FieldState st;
+    RTD_HIP(h, hipMemcpy(&st, f->dState, sizeof st, hipMemcpyDeviceToHost));
+    if (timing) {
+        std::memset(timing, 0, sizeof *timing);
+        RTD_HIP(h, hipEventElapsedTime(&timing->total_ms, f->ev[0], f->ev[6]));
+        if (h->opt.fine_grained_timing) {
+            RTD_HIP(h, hipEventElapsedTime(&timing->raytracing_ms, f->ev[0], f->ev[1]));
+            RTD_HIP(h, hipEventElapsedTime(&timing->prepare_energy_loop_ms, f->ev[1], f->ev[2]));
+            RTD_HIP(h, hipEventElapsedTime(&timing->fill_idd_sigma_ms, f->ev[2], f->ev[3]));
+            RTD_HIP(h, hipEventElapsedTime(&timing->prepare_superp_ms, f->ev[3], f->ev[4]));
+            RTD_HIP(h, hipEventElapsedTime(&timing->superp_ms, f->ev[4], f->ev[5]));
+            RTD_HIP(h, hipEventElapsedTime(&timing->transforming_ms, f->ev[5], f->ev[6]));
+        }
+        timing->superp_launches = 1;
+    }
+    if (info) {
+        std::memset(info, 0, sizeof *info);
+        info->ray_dims[0] = f->fc.W; info->ray_dims[1] = f->fc.H; info->ray_dims[2] = f->fc.L;
+        for (int i = 0; i < 3; ++i) { info->ray_offset[i] = f->fc.rayOffset[i]; info->ray_res[i] = f->fc.rayRes[i]; }
+        info->beam_first_inside = st.beamFirstInside; info->beam_first_outside = st.beamFirstOutside;
+        info->beam_first_guaranteed_passive = st.firstGuaranteedPassive;
+        info->beam_first_calculated_passive = st.firstCalculatedPassive;
+        for (int i = 0; i < 3; ++i) { info->bbox_min[i] = st.bboxMin[i]; info->bbox_max[i] = st.bboxMax[i]; }
+        info->live_steps = st.liveSteps; info->max_radius = st.maxRadius;
+    }
+    if (st.errorFlags & kErrRadiusOverflow)
+        return fail(h, RTD_ERR_RADIUS_OVERFLOW, "Found larger than allowed kernel superposition radius");   // kernel_wrapper.cu:965
+    if (st.errorFlags & kErrWorkOverflow) return fail(h, RTD_ERR_HIP, "superposition work list overflow");
+    return RTD_OK;
+}
+
+int rtd_field_fetch(rtd_handle hh, rtd_field ff, const char* name, void* host_out, size_t bytes, size_t* bytes_needed) {
+    auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
+    auto* f = reinterpret_cast<rtd_field_impl*>(ff);
+    if (!h || !f || !name) return RTD_ERR_INVALID_ARG;
+    const FieldConst& fc = f->fc;
+    const size_t R = f->R, S = fc.S, L = fc.L, tiles = (size_t)fc.tilesX * fc.tilesY;
+    const void* src = nullptr; size_t n = 0;
+    std::string nm(name);
+    std::vector<char> staging;
+    RTD_HIP(h, hipStreamSynchronize(h->stream));
+    if (nm == "density") { src = f->dDensity; n = 4 * R * S; }
+    else if (nm == "wepl") { src = f->dWepl; n = 4 * R * S; }
+    else if (nm == "first_inside") { src = f->dFirstInside; n = 4 * R; }
+    else if (nm == "first_outside") { src = f->dFirstOutside; n = 4 * R; }
+    else if (nm == "wepl_min") { src = f->dWeplMin; n = 4 * S; }
+    else if (nm == "ray_weights") { src = f->dRayWeights; n = 4 * R * L; }
+    else if (nm == "idd") { src = f->dIdd; n = 4 * R * S * L; }
+    else if (nm == "rsigma") { src = f->dRSigma; n = 4 * R * S * L; }
+    else if (nm == "first_passive") { src = f->dFirstPassive; n = 4 * R * L; }
+    else if (nm == "tile_radius") { src = f->dTileRad; n = L * S * tiles; }
+    else if (nm == "bev") { src = f->dBev; n = 4 * (size_t)fc.bevW * fc.bevH * S; }
+    else if (nm == "eff_radius" || nm == "layer_plan") {
+        std::vector<LayerPlan> lp(L);
+        RTD_HIP(h, hipMemcpy(lp.data(), f->dLayers, L * sizeof(LayerPlan), hipMemcpyDeviceToHost));
+        if (nm == "eff_radius") {
+            n = 4 * L * (kMaxSuperpR + 2); staging.resize(n);
+            for (size_t l = 0; l < L; ++l) std::memcpy(staging.data() + l * 4 * (kMaxSuperpR + 2), lp[l].effRad, 4 * (kMaxSuperpR + 2));
+        } else {
+            n = 4 * L * 8; staging.resize(n);
+            for (size_t l = 0; l < L; ++l) {
+                float v[8] = { lp[l].energyIdx, lp[l].energyScaleFact, lp[l].peakDepth, lp[l].entrySigmaX, lp[l].entrySigmaY,
+                               (float)lp[l].afterLast, (float)lp[l].layerFirstPassive, 0.0f };
+                std::memcpy(staging.data() + l * 32, v, 32);
+            }
+        }
+    } else return fail(h, RTD_ERR_INVALID_ARG, "rtd_field_fetch: unknown name " + nm);
+    if (bytes_needed) *bytes_needed = n;
+    if (!host_out) return RTD_OK;
+    if (bytes < n) return fail(h, RTD_ERR_INVALID_ARG, "rtd_field_fetch: buffer too small");
+    if (!staging.empty()) std::memcpy(host_out, staging.data(), n);
+    else RTD_HIP(h, hipMemcpy(host_out, src, n, hipMemcpyDeviceToHost));
+    return RTD_OK;
+}
+
+// The reference-shaped call (kernel_wrapper.cu:381-1369): dose up (:542), beam loop (:601), dose down (:1318).
+int rtd_compute(rtd_handle hh, const rtd_beam* beams, int n_beams, float* dose_inout, const uint32_t dose_dims[3], rtd_timing* timing) {
+    auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
+    if (!h || !beams || n_beams < 0 || !dose_inout || !dose_dims) return RTD_ERR_INVALID_ARG;
+    if (!h->dCt || !h->haveLuts) return fail(h, RTD_ERR_NOT_READY, "rtd_compute: set LUTs and CT first");
+    RTD_HIP(h, hipSetDevice(h->device));
+    const size_t n = (size_t)dose_dims[0] * dose_dims[1] * dose_dims[2];
+    float* dDose = nullptr;
+    RTD_HIP(h, hipMalloc((void**)&dDose, n * sizeof(float)));
+    int st = RTD_OK;
+    hipError_t e = hipMemcpyAsync(dDose, dose_inout, n * sizeof(float), hipMemcpyHostToDevice, h->stream);
+    if (e != hipSuccess) { h->error = hipGetErrorString(e); st = RTD_ERR_HIP; }
+    for (int i = 0; i < n_beams && st == RTD_OK; ++i) {
+        rtd_field f = nullptr;
+        st = rtd_field_create(hh, &beams[i], dose_dims, &f);
+        if (st != RTD_OK) break;
+        st = rtd_field_compute(hh, f, dDose);
+        if (st == RTD_OK) st = rtd_field_finish(hh, f, timing ? &timing[i] : nullptr, nullptr);
+        std::string keep = h->error;
+        rtd_field_destroy(hh, f);
+        h->error = keep;
+    }
+    if (st == RTD_OK) {
+        e = hipMemcpyAsync(dose_inout, dDose, n * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) { h->error = hipGetErrorString(e); st = RTD_ERR_HIP; }
+    }
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(dDose);
+    return st;
+}
+
+}  // extern "C"

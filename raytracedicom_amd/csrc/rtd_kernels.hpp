@@ -1,0 +1,566 @@
+// rtd_kernels.hpp — hand-written HIP kernels (gfx950 / CDNA4, wave64) of the pencil-beam dose path.
+//
+// One kernel per stage of the reference's cudaWrapperProtons (src/kernel_wrapper.cu:381-1369). There are no
+// texture units on gfx950: every CT / LUT / BEV interpolation is written out against plain global or LDS
+// memory with the BORDER / CLAMP semantics of the reference's samplers (kernel_wrapper.cu:418-537).
+// All control scalars (entry step, cut-off steps, tile-radius histograms, work lists, bounding box) stay
+// on the device, so a field is a fixed sequence of launches with no host round trip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "rtd_geometry.hpp"
+
+namespace rtd {
+
+constexpr int kWave = 64;
+constexpr int kMaxLayers = 256;
+constexpr int kMaxSteps = 4096;
+constexpr int kMaxTiles = 4096;
+constexpr int kNoRadius = 0xFF;
+
+enum FieldError : int { kErrRadiusOverflow = 1, kErrWorkOverflow = 2 };
+
+struct LutView {
+    const float* density; int nDensity;
+    const float* sp; int nSp;
+    const float* rrl; int nRrl;
+    const float* cidd; int nSamples; int nEnergies;
+};
+
+// Per-layer record. Host fills the beam-model part at field creation; k_plan / k_fill / k_ks_plan fill the rest.
+struct LayerPlan {
+    float energyIdx, energyScaleFact, peakDepth;       // kernel_wrapper.cu:834-837
+    float spotSigmaX, spotSigmaY;                      // BeamSettings::getSpotSigmas
+    float airCoefA, airCoefB;                          // sigmaSqAirCoefs(peakDepth)  fill_idd_and_sigma_params.cu:74-83
+    float sigmaSqAirLin, sigmaSqAirQuad;               // initStepAndAirDiv           fill_idd_and_sigma_params.cu:28-40
+    float entrySigmaX, entrySigmaY;                    // kernel_wrapper.cu:838-841   (device)
+    int afterLast;                                     // kernel_wrapper.cu:923-924   (device)
+    int layerFirstPassive;                             // kernel_wrapper.cu:952-957   (device, atomicMax)
+    int hist[kMaxSuperpR + 2];                         // tilePrimRadCtrs             kernel_wrapper.cu:959-963
+    int effRad[kMaxSuperpR + 2];                       // batch radius per tile radius kernel_wrapper.cu:966-976
+};
+
+struct FieldState {
+    int beamFirstInside;            // kernel_wrapper.cu:781-784
+    int beamFirstOutside;           // :785-787
+    int firstGuaranteedPassive;     // :796
+    int firstCalculatedPassive;     // :955-957
+    float entryZ, pxSpMultX, pxSpMultY;   // :784, :849
+    int errorFlags;
+    int maxRadius;
+    unsigned int workCount;
+    long long liveSteps;
+    int bboxMin[3], bboxMax[3];     // :1207-1208
+    TransferParams transfer;        // :1213
+    int empty;                      // nothing inside the patient for this beam
+};
+
+// Host-known per-field constants, passed by value.
+struct FieldConst {
+    int W, H, L, S;                 // ray grid (primRayDims) and tracer steps
+    int bevW, bevH;                 // W+64, H+64
+    int tilesX, tilesY;
+    float rayRes[3], rayOffset[3];
+    float sourceDist[2];
+    int spotNx, spotNy;
+    float spotDelta[3], spotOffset[3];
+    float maxPeakDepth;             // kernel_wrapper.cu:792-794
+    float bpDepthCutoff, convSigmaCutoff, ksSigmaCutoff, rayWeightCutoff;
+    int doseToWater, nozzle;
+    unsigned int workCapacity;
+};
+
+// ------------------------------------------------------------------------------------------------
+// wave64 helpers
+__device__ inline float waveMin(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { float t = __shfl_xor(v, o, kWave); v = t < v ? t : v; }
+    return v;
+}
+__device__ inline int waveMinI(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o, kWave); v = t < v ? t : v; }
+    return v;
+}
+__device__ inline int waveMaxI(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o, kWave); v = t > v ? t : v; }
+    return v;
+}
+__device__ inline int f2iSat(float v) { return (int)v; }   // v_cvt_i32_f32: NaN -> 0, saturating (same as the reference GPU)
+
+// ------------------------------------------------------------------------------------------------
+// Software samplers (replace tex1D/tex2D/tex3D, kernel_wrapper.cu:418-537). p = coordinate without the +0.5.
+__device__ inline float lerpW(float a, float v0, float v1) { return (1.0f - a) * v0 + a * v1; }
+
+template <typename Ptr>
+__device__ inline float sample1dClamp(Ptr t, int n, float p) {
+    float fl = floorf(p);
+    float a = p - fl;
+    int i0 = (int)fl, i1 = i0 + 1;
+    if (!(p >= 0.0f)) { i0 = 0; i1 = 0; a = 0.0f; }
+    i0 = i0 > n - 1 ? n - 1 : i0;
+    i1 = i1 > n - 1 ? n - 1 : i1;
+    return lerpW(a, t[i0], t[i1]);
+}
+__device__ inline float sample2dClamp(const float* __restrict__ t, int ncol, int nrow, float px, float py) {
+    float fx = floorf(px), fy = floorf(py);
+    float ax = px - fx, ay = py - fy;
+    int x0 = (int)fx, x1 = x0 + 1, y0 = (int)fy, y1 = y0 + 1;
+    if (!(px >= 0.0f)) { x0 = 0; x1 = 0; ax = 0.0f; }
+    if (!(py >= 0.0f)) { y0 = 0; y1 = 0; ay = 0.0f; }
+    x0 = x0 > ncol - 1 ? ncol - 1 : x0; x1 = x1 > ncol - 1 ? ncol - 1 : x1;
+    y0 = y0 > nrow - 1 ? nrow - 1 : y0; y1 = y1 > nrow - 1 ? nrow - 1 : y1;
+    float r0 = lerpW(ax, t[(size_t)y0 * ncol + x0], t[(size_t)y0 * ncol + x1]);
+    float r1 = lerpW(ax, t[(size_t)y1 * ncol + x0], t[(size_t)y1 * ncol + x1]);
+    return lerpW(ay, r0, r1);
+}
+__device__ inline float fetch3dBorder(const float* __restrict__ vol, int nx, int ny, int nz, int x, int y, int z) {
+    bool in = (unsigned)x < (unsigned)nx && (unsigned)y < (unsigned)ny && (unsigned)z < (unsigned)nz;
+    size_t idx = in ? ((size_t)z * ny + y) * nx + x : 0;
+    float v = vol[idx];
+    return in ? v : 0.0f;
+}
+__device__ inline float sample3dBorder(const float* __restrict__ vol, int nx, int ny, int nz, float px, float py, float pz) {
+    if (!(px > -1.0f && py > -1.0f && pz > -1.0f && px < (float)nx && py < (float)ny && pz < (float)nz)) return 0.0f;
+    float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+    float ax = px - fx, ay = py - fy, az = pz - fz;
+    int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    float c00 = lerpW(ax, fetch3dBorder(vol, nx, ny, nz, x0, y0, z0), fetch3dBorder(vol, nx, ny, nz, x0 + 1, y0, z0));
+    float c10 = lerpW(ax, fetch3dBorder(vol, nx, ny, nz, x0, y0 + 1, z0), fetch3dBorder(vol, nx, ny, nz, x0 + 1, y0 + 1, z0));
+    float c01 = lerpW(ax, fetch3dBorder(vol, nx, ny, nz, x0, y0, z0 + 1), fetch3dBorder(vol, nx, ny, nz, x0 + 1, y0, z0 + 1));
+    float c11 = lerpW(ax, fetch3dBorder(vol, nx, ny, nz, x0, y0 + 1, z0 + 1), fetch3dBorder(vol, nx, ny, nz, x0 + 1, y0 + 1, z0 + 1));
+    float c0 = lerpW(ay, c00, c10);
+    float c1 = lerpW(ay, c01, c11);
+    return lerpW(az, c0, c1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K0: reset the per-field device state (the reference re-creates these per beam, kernel_wrapper.cu:685-734).
+__global__ void k_reset(FieldState* st, LayerPlan* layers, int L, int* weplMinBits, int S) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) {
+        st->beamFirstInside = 0x7fffffff; st->beamFirstOutside = -0x7fffffff; st->firstGuaranteedPassive = 0;
+        st->firstCalculatedPassive = 0; st->errorFlags = 0; st->maxRadius = 0; st->workCount = 0; st->liveSteps = 0;
+        st->empty = 0;
+        for (int i = 0; i < 3; ++i) { st->bboxMin[i] = 0; st->bboxMax[i] = 0; }
+    }
+    for (int k = t; k < S; k += gridDim.x * blockDim.x) weplMinBits[k] = 0x7f800000;  // +inf
+    for (int l = t; l < L; l += gridDim.x * blockDim.x) {
+        layers[l].layerFirstPassive = 0; layers[l].afterLast = 0;
+        for (int i = 0; i < kMaxSuperpR + 2; ++i) { layers[l].hist[i] = 0; layers[l].effRad[i] = i; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: ray tracer = fillBevDensityAndSp (kernel_wrapper.cu:130-187) fused with the three reductions that follow
+// it in the reference (sliceMinVar/sliceMaxVar, kernel_wrapper.cu:781-790): per-step min WEPL, min firstInside,
+// max firstOutside. One thread per ray, block = one 32x8 tile of rays = 4 waves; the two HU LUTs live in LDS.
+// Stores are step-major and coalesced (32 consecutive floats per row).
+__global__ __launch_bounds__(256) void k_trace(const float* __restrict__ ct, int nx, int ny, int nz, LutView lut,
+                                                TracerParams tp, int W, int H, float* __restrict__ bevDensity,
+                                                float* __restrict__ bevCumulSp, int* __restrict__ firstInside,
+                                                int* __restrict__ firstOutside, int* __restrict__ weplMinBits,
+                                                FieldState* st) {
+    extern __shared__ float sLut[];
+    float* sDensity = sLut;
+    float* sSp = sLut + lut.nDensity;
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    for (int i = tid; i < lut.nDensity; i += 256) sDensity[i] = lut.density[i];
+    for (int i = tid; i < lut.nSp; i += 256) sSp[i] = lut.sp[i];
+    __syncthreads();
+
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    const size_t memStep = (size_t)W * H;
+    size_t idx = (size_t)y * W + x;
+
+    Vec3 pos = tp.getStart(x, y);     // texel-centre +0.5 of kernel_wrapper.cu:142 is implicit in the sampler
+    const Vec3 step = tp.getInc(x, y);
+    const float stepLen = tp.stepLen(x, y);
+    float cumulSp = 0.0f, cumulHuPlus1000 = 0.0f;
+    int beforeFirstInside = -1, lastInside = -1;
+
+    for (unsigned int i = 0; i < tp.steps; ++i) {
+        float huPlus1000 = sample3dBorder(ct, nx, ny, nz, pos.x, pos.y, pos.z);
+        cumulHuPlus1000 += huPlus1000;
+        bevDensity[idx] = sample1dClamp(sDensity, lut.nDensity, huPlus1000 * tp.densityScale);
+        cumulSp += stepLen * sample1dClamp(sSp, lut.nSp, huPlus1000 * tp.spScale);
+        if (cumulHuPlus1000 < 150.0f) beforeFirstInside = (int)i;
+        if (huPlus1000 > 150.0f) lastInside = (int)i;
+        bevCumulSp[idx] = cumulSp;
+        // fused sliceMinVar<float> over this step (WEPL >= 0, so the int order of the bit pattern is the float order)
+        float m = waveMin(cumulSp);
+        if ((tid & (kWave - 1)) == 0) atomicMin(&weplMinBits[i], __float_as_int(m));
+        idx += memStep;
+        pos = pos + step;
+    }
+    firstInside[(size_t)y * W + x] = beforeFirstInside + 1;
+    firstOutside[(size_t)y * W + x] = lastInside + 1;
+    int mn = waveMinI(beforeFirstInside + 1), mx = waveMaxI(lastInside + 1);
+    if ((tid & (kWave - 1)) == 0) { atomicMin(&st->beamFirstInside, mn); atomicMax(&st->beamFirstOutside, mx); }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: device-side plan = the host cut-off logic of kernel_wrapper.cu:784,792-802,829-849,923-924.
+__global__ void k_plan(FieldState* st, LayerPlan* layers, const int* weplMinBits, FieldConst fc) {
+    const float* weplMin = reinterpret_cast<const float*>(weplMinBits);
+    __shared__ int sGuaranteed;
+    __shared__ float sEntryZ;
+    if (threadIdx.x == 0) {
+        int first = st->beamFirstInside;
+        float entryZ = ((float)first) * fc.rayRes[2] + fc.rayOffset[2];
+        int firstPastCutoffAll = findFirstLargerOrdered(weplMin, fc.S, fc.bpDepthCutoff * fc.maxPeakDepth);
+        int guaranteed = firstPastCutoffAll < st->beamFirstOutside ? firstPastCutoffAll : st->beamFirstOutside;
+        st->firstGuaranteedPassive = guaranteed;
+        st->entryZ = entryZ;
+        st->pxSpMultX = 1.0f - entryZ / fc.sourceDist[0];
+        st->pxSpMultY = 1.0f - entryZ / fc.sourceDist[1];
+        st->empty = guaranteed > first ? 0 : 1;
+        sGuaranteed = guaranteed; sEntryZ = entryZ;
+    }
+    __syncthreads();
+    const float entryZ = sEntryZ;
+    for (int l = threadIdx.x; l < fc.L; l += blockDim.x) {
+        LayerPlan& p = layers[l];
+        p.entrySigmaX = sqrtf(p.airCoefA * entryZ * entryZ + p.airCoefB * entryZ + p.spotSigmaX * p.spotSigmaX);
+        p.entrySigmaY = sqrtf(p.airCoefA * entryZ * entryZ + p.airCoefB * entryZ + p.spotSigmaY * p.spotSigmaY);
+        unsigned int localAfterLast = (unsigned int)findFirstLargerOrdered(weplMin, fc.S, fc.bpDepthCutoff * p.peakDepth);
+        unsigned int g = (unsigned int)sGuaranteed;
+        p.afterLast = (int)(localAfterLast < g ? localAfterLast : g);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3/K4: spot -> ray weights, separable erf-integrated Gaussian resampling (gpu_convolution_2d.cu:16-59).
+__global__ void k_conv_x(const float* __restrict__ in, float* __restrict__ out, const LayerPlan* __restrict__ layers,
+                         const FieldState* __restrict__ st, FieldConst fc) {
+    const int idxY = blockDim.y * blockIdx.y + threadIdx.y;
+    const int z = blockIdx.z;
+    const int inWidth = fc.spotNx, height = fc.spotNy, outWidth = fc.W;
+    const float inOutDelta = fc.spotDelta[0] / fc.rayRes[0];
+    const float inOutOffset = (fc.spotOffset[0] - fc.rayOffset[0]) / fc.rayRes[0];
+    const float pixelSp = fc.rayRes[0] * st->pxSpMultX;
+    const float cut = fc.convSigmaCutoff;
+    if (idxY < height) {
+        const int outIdxX = blockDim.x * blockIdx.x + threadIdx.x;
+        float res = 0.0f;
+        float sigmaEff = layers[z].entrySigmaX / pixelSp;
+        float rSigmaEff = (1.0f / sqrtf(2.0f)) / sigmaEff;
+        int cur = f2iSat(ceilf(((float)outIdxX - (cut * sigmaEff + 0.5f) - inOutOffset) / inOutDelta));
+        cur = cur < 0 ? 0 : cur;   // spots left of the map contribute nothing: skip them (bounded loop, same result)
+        float dist = (float)cur * inOutDelta + inOutOffset - (float)outIdxX;
+        while (dist < (cut * sigmaEff + 0.5f) && cur < inWidth) {
+            if (cur >= 0 && cur < inWidth)
+                res += 0.5f * (erff((dist + 0.5f) * rSigmaEff) - erff((dist - 0.5f) * rSigmaEff))
+                       * in[(size_t)z * inWidth * height + (size_t)idxY * inWidth + cur];
+            ++cur;
+            dist = (float)cur * inOutDelta + inOutOffset - (float)outIdxX;
+        }
+        out[(size_t)z * outWidth * height + (size_t)idxY * outWidth + outIdxX] = res;
+    }
+}
+__global__ void k_conv_y(const float* __restrict__ in, float* __restrict__ out, const LayerPlan* __restrict__ layers,
+                         const FieldState* __restrict__ st, FieldConst fc) {
+    const int idxX = blockDim.x * blockIdx.x + threadIdx.x;
+    const int z = blockIdx.z;
+    const int width = fc.W, inHeight = fc.spotNy, outHeight = fc.H;
+    const float inOutDelta = fc.spotDelta[1] / fc.rayRes[1];
+    const float inOutOffset = (fc.spotOffset[1] - fc.rayOffset[1]) / fc.rayRes[1];
+    const float pixelSp = fc.rayRes[1] * st->pxSpMultY;
+    const float cut = fc.convSigmaCutoff;
+    if (idxX < width) {
+        const int outIdxY = blockDim.y * blockIdx.y + threadIdx.y;
+        float res = 0.0f;
+        float sigmaEff = layers[z].entrySigmaY / pixelSp;
+        float rSigmaEff = (1.0f / sqrtf(2.0f)) / sigmaEff;
+        int cur = f2iSat(ceilf(((float)outIdxY - (cut * sigmaEff + 0.5f) - inOutOffset) / inOutDelta));
+        cur = cur < 0 ? 0 : cur;
+        float dist = (float)cur * inOutDelta + inOutOffset - (float)outIdxY;
+        while (dist < (cut * sigmaEff + 0.5f) && cur < inHeight) {
+            if (cur >= 0 && cur < inHeight)
+                res += 0.5f * (erff((dist + 0.5f) * rSigmaEff) - erff((dist - 0.5f) * rSigmaEff))
+                       * in[(size_t)z * width * inHeight + (size_t)cur * width + idxX];
+            ++cur;
+            dist = (float)cur * inOutDelta + inOutOffset - (float)outIdxY;
+        }
+        out[(size_t)z * width * outHeight + (size_t)outIdxY * width + idxX] = res;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5: IDD + sigma fill = fillIddAndSigma without NUCLEAR_CORR (kernel_wrapper.cu:190-379), all energy layers in
+// one launch (blockIdx.z = layer), fused with the reductions and the classification that follow it in the
+// reference: layerFirstPassive (sliceMaxVar, :952-957), the per-tile radius class + histogram (tileRadCalc,
+// kernel_wrapper.cuh:256-313) and the list of tiles that hold dose (replaces the per-radius tile lists).
+// Block = one 32x8 classification tile = 4 waves; the serial recurrence along the ray is kept in the
+// reference's order ("a bit of a mine field", kernel_wrapper.cuh:144).
+__global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensity, const float* __restrict__ bevCumulSp,
+                                               float* __restrict__ bevIdd, float* __restrict__ bevRSigmaEff,
+                                               const float* __restrict__ rayWeights, const int* __restrict__ firstInside,
+                                               const int* __restrict__ firstOutside, int* __restrict__ firstPassive,
+                                               unsigned char* __restrict__ tileRad, unsigned int* __restrict__ workList,
+                                               LayerPlan* layers, FieldState* st, LutView lut, FillGeom fg, FieldConst fc) {
+    __shared__ float sMin[2][4];
+    __shared__ int sAny[2][4];
+    __shared__ int sHist[kMaxSuperpR + 2];
+    __shared__ unsigned int sItems[kMaxSteps];
+    __shared__ int sItemCount;
+    __shared__ unsigned int sBase;
+
+    const int layer = blockIdx.z;
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    const int wave = tid >> 6;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    const int W = fc.W, H = fc.H;
+    const size_t memStep = (size_t)W * H;
+    const size_t layerOff = (size_t)layer * memStep * fc.S;
+    const size_t rayIdx = (size_t)y * W + x;
+    size_t idx = rayIdx;
+
+    if (tid < kMaxSuperpR + 2) sHist[tid] = 0;
+    if (tid == 0) sItemCount = 0;
+
+    const LayerPlan lp = layers[layer];
+    const unsigned int pFirst = (unsigned int)st->beamFirstInside;
+    const unsigned int pAfterLast = st->empty ? pFirst : (unsigned int)lp.afterLast;
+
+    bool beamLive = true;
+    const int firstIn = firstInside[rayIdx];
+    int fo = firstOutside[rayIdx];
+    unsigned int afterLast = (unsigned int)(fo < (int)pAfterLast ? fo : (int)pAfterLast);
+    const float rayWeight = rayWeights[(size_t)layer * memStep + rayIdx];
+    if (rayWeight < fc.rayWeightCutoff || afterLast < pFirst) { beamLive = false; afterLast = 0; }
+
+    float res = 0.0f, rSigmaEff = 0.0f, cumulSp, cumulSpOld = 0.0f, cumulDose, cumulDoseOld = 0.0f;
+    const float pInv = 0.5649718f, eCoef = 8.639415f, sqrt2 = 1.41421356f;
+    const float eRefSq = 198.81f, sigmaDelta = 0.21f;
+    float incScat = 0.0f, incincScat = 0.0f;
+    float incDiv = lp.sigmaSqAirLin + (2.0f * (float)pFirst - 1.0f) * lp.sigmaSqAirQuad;
+    float sigmaSq = -incDiv;
+    const int tileNo = blockIdx.y * gridDim.x + blockIdx.x;
+    const int nTiles = gridDim.x * gridDim.y;
+    __syncthreads();
+
+    idx += (size_t)pFirst * memStep;
+    for (unsigned int stepNo = pFirst; stepNo < pAfterLast; ++stepNo) {
+        if (beamLive) {
+            cumulSp = bevCumulSp[idx];
+            cumulDose = sample2dClamp(lut.cidd, lut.nSamples, lut.nEnergies, cumulSp * lp.energyScaleFact, lp.energyIdx);
+            float density = bevDensity[idx];
+            if (cumulSp < lp.peakDepth) {
+                float resE = eCoef * powf(lp.peakDepth - 0.5f * (cumulSp + cumulSpOld), pInv);
+                float betaP = resE + 938.3f - 938.3f * 938.3f / (resE + 938.3f);
+                float rRl = density * sample1dClamp(lut.rrl, lut.nRrl, density * fg.rRlScale);
+                float thetaSq = eRefSq / (betaP * betaP) * fg.stepLength * rRl;
+                sigmaSq += incScat + incDiv;
+                incincScat += 2.0f * thetaSq * fg.stepLength * fg.stepLength;
+                incScat += incincScat;
+                incDiv += 2.0f * lp.sigmaSqAirQuad;
+            } else {
+                sigmaSq -= 1.5f * (incScat + incDiv) * density;
+            }
+            Vec2 vw = fg.voxelWidth(stepNo);
+            rSigmaEff = 0.5f * (vw.x + vw.y) / (sqrt2 * (sqrtf(sigmaSq) + sigmaDelta));
+            if (cumulSp > lp.peakDepth * fc.bpDepthCutoff || stepNo == afterLast) { beamLive = false; afterLast = stepNo; }
+            float mass = fc.doseToWater ? (cumulSp - cumulSpOld) * fg.stepVol(stepNo) : density * fg.stepVol(stepNo);
+            if (mass > 1e-2f) res = rayWeight * (cumulDose - cumulDoseOld) / mass;
+            cumulSpOld = cumulSp;
+            cumulDoseOld = cumulDose;
+        }
+        if (!beamLive || (int)stepNo < (firstIn - 1)) { res = 0.0f; rSigmaEff = __int_as_float(0x7f800000); }
+        bevIdd[layerOff + idx] = res;
+        bevRSigmaEff[layerOff + idx] = rSigmaEff;
+
+        // fused tileRadCalc: min of 1/sigma over the 32x8 tile -> radius class; any(dose>0) -> work item
+        const int buf = stepNo & 1;
+        float wm = waveMin(rSigmaEff);
+        int wa = __any(res > 0.0f);
+        if ((tid & (kWave - 1)) == 0) { sMin[buf][wave] = wm; sAny[buf][wave] = wa; }
+        __syncthreads();
+        if (tid == 0) {
+            float m = sMin[buf][0];
+            m = sMin[buf][1] < m ? sMin[buf][1] : m; m = sMin[buf][2] < m ? sMin[buf][2] : m; m = sMin[buf][3] < m ? sMin[buf][3] : m;
+            int rad = f2iSat(fc.ksSigmaCutoff / (sqrtf(2.0f) * m) + 0.5f);
+            rad = rad > kMaxSuperpR + 1 ? kMaxSuperpR + 1 : rad;
+            rad = rad < 0 ? 0 : rad;
+            tileRad[((size_t)layer * fc.S + stepNo) * nTiles + tileNo] = (unsigned char)rad;
+            sHist[rad] += 1;
+            if (sAny[buf][0] | sAny[buf][1] | sAny[buf][2] | sAny[buf][3])
+                sItems[sItemCount++] = ((unsigned int)layer << 24) | (stepNo << 12) | (unsigned int)tileNo;
+        }
+        idx += memStep;
+    }
+    firstPassive[(size_t)layer * memStep + rayIdx] = (int)afterLast;
+    int mx = waveMaxI((int)afterLast);
+    if ((tid & (kWave - 1)) == 0) atomicMax(&layers[layer].layerFirstPassive, mx);
+    __syncthreads();
+    if (tid < kMaxSuperpR + 2 && sHist[tid] > 0) atomicAdd(&layers[layer].hist[tid], sHist[tid]);
+    if (tid == 0) {
+        unsigned int base = sItemCount ? atomicAdd(&st->workCount, (unsigned int)sItemCount) : 0u;
+        if (base + (unsigned int)sItemCount > fc.workCapacity) { atomicOr(&st->errorFlags, kErrWorkOverflow); sItemCount = 0; }
+        sBase = base;
+    }
+    __syncthreads();
+    for (int i = tid; i < sItemCount; i += 256) workList[sBase + i] = sItems[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6: superposition plan = host batching of radii (kernel_wrapper.cu:965-976) + beamFirstCalculatedPassive
+// (:955-957) + transfer bounding box and shift (:1185-1213), all on the device.
+__global__ void k_ks_plan(FieldState* st, LayerPlan* layers, FieldConst fc, FromFan rayIdxToDoseIdx, TransferParams tp0,
+                          int doseNx, int doseNy, int doseNz) {
+    __shared__ int sMaxPassive;
+    __shared__ int sMaxRad;
+    __shared__ unsigned long long sLive;
+    if (threadIdx.x == 0) { sMaxPassive = 0; sMaxRad = 0; sLive = 0ull; }
+    __syncthreads();
+    const int first = st->beamFirstInside;
+    for (int l = threadIdx.x; l < fc.L; l += blockDim.x) {
+        LayerPlan& p = layers[l];
+        int layerMax = 0;
+        for (int i = 0; i < kMaxSuperpR + 2; ++i) if (p.hist[i] > 0) layerMax = i;
+        // tiles at steps >= layerFirstPassive are not classified by the reference; they can only be radius 0
+        if (p.hist[kMaxSuperpR + 1] > 0) atomicOr(&st->errorFlags, kErrRadiusOverflow);
+        for (int i = 0; i < kMaxSuperpR + 2; ++i) p.effRad[i] = i;
+        if (layerMax <= kMaxSuperpR) {
+            int rec = layerMax, batched = 0;
+            for (int rad = layerMax; rad > 0; --rad) {
+                batched += p.hist[rad];
+                p.effRad[rad] = rec;
+                if (batched >= kMinTilesInBatch) { rec = rad - 1; batched = 0; }
+            }
+        }
+        atomicMax(&sMaxRad, layerMax);
+        atomicMax(&sMaxPassive, p.layerFirstPassive);
+        if (p.layerFirstPassive > first) atomicAdd(&sLive, (unsigned long long)(p.layerFirstPassive - first));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int calcPassive = sMaxPassive;
+        st->firstCalculatedPassive = calcPassive;
+        st->maxRadius = sMaxRad;
+        st->liveSteps = (long long)sLive;
+        TransferParams tp = tp0;
+        tp.globalOffset.z = tp0.globalOffset.z + (-(float)first);   // invertAndShift(..., -beamFirstInside) :1213
+        st->transfer = tp;
+        if (calcPassive > first) {
+            Vec3 maxP = v3(-1.0f, -1.0f, -1.0f), minP = v3(100000.0f, 100000.0f, 100000.0f);
+            float xVals[2] = { -(float)kMaxSuperpR, (float)(fc.W + kMaxSuperpR - 1) };
+            float yVals[2] = { -(float)kMaxSuperpR, (float)(fc.H + kMaxSuperpR - 1) };
+            float zVals[2] = { (float)first, (float)(calcPassive - 1) };
+            for (int zi = 0; zi < 2; ++zi) for (int yi = 0; yi < 2; ++yi) for (int xi = 0; xi < 2; ++xi) {
+                Vec3 p = transformPoint(rayIdxToDoseIdx, v3(xVals[xi], yVals[yi], zVals[zi]));
+                if (p.x > maxP.x) maxP.x = p.x; if (p.y > maxP.y) maxP.y = p.y; if (p.z > maxP.z) maxP.z = p.z;
+                if (p.x < minP.x) minP.x = p.x; if (p.y < minP.y) minP.y = p.y; if (p.z < minP.z) minP.z = p.z;
+            }
+            int t;
+            t = (((int)floorf(minP.x)) / 32) * 32; st->bboxMin[0] = t > 0 ? t : 0;
+            t = (int)floorf(minP.y); st->bboxMin[1] = t > 0 ? t : 0;
+            t = (int)floorf(minP.z); st->bboxMin[2] = t > 0 ? t : 0;
+            t = (int)ceilf(maxP.x); st->bboxMax[0] = t < doseNx - 1 ? t : doseNx - 1;
+            t = (int)ceilf(maxP.y); st->bboxMax[1] = t < doseNy - 1 ? t : doseNy - 1;
+            t = (int)ceilf(maxP.z); st->bboxMax[2] = t < doseNz - 1 ? t : doseNz - 1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7 (v1): kernel superposition = kernelSuperposition<rad> (kernel_wrapper.cuh:432-489). One work item = one
+// 32x8 source tile at one (layer, step) that holds dose. Persistent blocks stride over the device-side work
+// list; the extent radius is the batch radius effRad[tileRad] exactly as the reference's batched launches.
+// Per source voxel: erf-difference weights e[0..rad] (LDS table, one row per thread), then (2rad+1)^2 LDS
+// float atomic adds into the block's (32+2rad)x(8+2rad) tile, then a flush with global float atomics.
+__global__ __launch_bounds__(256) void k_superpose(const float* __restrict__ bevIdd, const float* __restrict__ bevRSigmaEff,
+                                                    float* __restrict__ bevDose, const unsigned char* __restrict__ tileRad,
+                                                    const unsigned int* __restrict__ workList, const LayerPlan* __restrict__ layers,
+                                                    const FieldState* __restrict__ st, FieldConst fc) {
+    constexpr int TW = kSuperpTileX + 2 * kMaxSuperpR;   // 96
+    constexpr int TH = kSuperpTileY + 2 * kMaxSuperpR;   // 72
+    constexpr int ES = kMaxSuperpR + 2;                  // table stride 34 (odd number of dwords would be 33; 34 keeps 8B alignment)
+    __shared__ float tile[TW * TH];
+    __shared__ float eTab[256 * ES];
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    const unsigned int count = st->workCount < fc.workCapacity ? st->workCount : fc.workCapacity;
+    const size_t memStep = (size_t)fc.W * fc.H;
+    const int nTiles = fc.tilesX * fc.tilesY;
+    const int outPitch = fc.bevW;
+    const size_t outSlice = (size_t)fc.bevW * fc.bevH;
+
+    for (unsigned int w = blockIdx.x; w < count; w += gridDim.x) {
+        const unsigned int item = workList[w];
+        const int layer = item >> 24, k = (item >> 12) & 0xFFF, tileNo = item & 0xFFF;
+        const int ownRad = tileRad[((size_t)layer * fc.S + k) * nTiles + tileNo];
+        if (ownRad > kMaxSuperpR) continue;                  // overflow is reported through errorFlags
+        const int rad = layers[layer].effRad[ownRad];
+        const int tw = kSuperpTileX + 2 * rad, th = kSuperpTileY + 2 * rad;
+        const int bx = tileNo % fc.tilesX, by = tileNo / fc.tilesX;
+        for (int i = tid; i < tw * th; i += 256) tile[i] = 0.0f;
+
+        const size_t inIdx = (size_t)layer * memStep * fc.S + (size_t)k * memStep
+                             + (size_t)(by * kSuperpTileY + threadIdx.y) * fc.W + bx * kSuperpTileX + threadIdx.x;
+        const float dose = bevIdd[inIdx];
+        const float rSigmaEff = bevRSigmaEff[inIdx];
+        float* e = eTab + tid * ES;
+        {   // erfDiffs (kernel_wrapper.cuh:459-467)
+            float erfNew = erff(rSigmaEff * 0.5f);
+            float erfOld = -erfNew;
+            for (int i = 0; i <= rad; ++i) {
+                e[i] = 0.5f * (erfNew - erfOld);
+                erfOld = erfNew;
+                erfNew = erff(rSigmaEff * ((float)i + 1.5f));
+            }
+        }
+        __syncthreads();
+        const int row = threadIdx.y, col = threadIdx.x;
+        for (int i = 0; i < 2 * rad + 1; ++i) {
+            const float wi = dose * e[abs(rad - i)];
+            float* trow = tile + (row + i) * tw + col;
+            for (int j = 0; j < 2 * rad + 1; ++j) {
+                __hip_atomic_fetch_add(trow + j, wi * e[abs(rad - j)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        __syncthreads();
+        // flush (kernel_wrapper.cuh:480-488): tile element (r, c) -> bev[k][by*8 + r + 32 - rad][bx*32 + c + 32 - rad]
+        float* out = bevDose + (size_t)k * outSlice + (size_t)(by * kSuperpTileY + kMaxSuperpR - rad) * outPitch
+                     + bx * kSuperpTileX + kMaxSuperpR - rad;
+        for (int i = tid; i < tw * th; i += 256) {
+            int r = i / tw, c = i - r * tw;
+            float v = tile[i];
+            if (v != 0.0f) unsafeAtomicAdd(out + (size_t)r * outPitch + c, v);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K8: fan -> dose-grid transfer = primTransfDiv (kernel_wrapper.cu:69-97). The reference copies the BEV slab
+// into a 3-D texture first (:1107-1141); here the trilinear BORDER sample is taken from the BEV buffer itself
+// (slab origin and extent applied in index arithmetic), which removes that copy. One thread per dose (x,y)
+// column inside the device-side bounding box, walking z.
+__global__ __launch_bounds__(256) void k_transfer(float* __restrict__ dose, int nx, int ny, int nz,
+                                                   const float* __restrict__ bevDose, const FieldState* __restrict__ st,
+                                                   FieldConst fc) {
+    const int first = st->beamFirstInside;
+    const int slabZ = st->firstCalculatedPassive - first;
+    if (slabZ <= 0) return;
+    const int x = st->bboxMin[0] + blockDim.x * blockIdx.x + threadIdx.x;
+    const int y = st->bboxMin[1] + blockDim.y * blockIdx.y + threadIdx.y;
+    const int xEnd = st->bboxMin[0] + ((st->bboxMax[0] - st->bboxMin[0] + 1 + 31) / 32) * 32;
+    if (x >= xEnd || y > st->bboxMax[1] || x >= nx || y >= ny) return;
+    TransferParams p = st->transfer;
+    p.init(x, y);
+    const float* slab = bevDose + (size_t)first * fc.bevW * fc.bevH;
+    const int z0 = st->bboxMin[2], z1 = st->bboxMax[2];
+    float* res = dose + (size_t)z0 * nx * ny + (size_t)y * nx + x;
+    for (int z = z0; z <= z1; ++z) {
+        Vec3 pos = p.getFanIdx(z);
+        float tmp = sample3dBorder(slab, fc.bevW, fc.bevH, slabZ, pos.x, pos.y, pos.z);
+        if (tmp > 0.0f) *res += tmp;
+        res += (size_t)nx * ny;
+    }
+}
+
+}  // namespace rtd
