@@ -472,14 +472,14 @@ __global__ void k_ks_plan(FieldState* st, LayerPlan* layers, FieldConst fc, From
 // 32x8 source tile at one (layer, step) that holds dose. Persistent blocks stride over the device-side work
 // list; the extent radius is the batch radius effRad[tileRad] exactly as the reference's batched launches.
 // Per source voxel: erf-difference weights e[0..rad] (LDS table, one row per thread), then (2rad+1)^2 LDS
-// float atomic adds into the block's (32+2rad)x(8+2rad) tile, then a flush with global float atomics.
+// LDS read-modify-writes into the block's (32+2rad)x(8+2rad) tile, then a flush with global float atomics.
 __global__ __launch_bounds__(256) void k_superpose(const float* __restrict__ bevIdd, const float* __restrict__ bevRSigmaEff,
                                                     float* __restrict__ bevDose, const unsigned char* __restrict__ tileRad,
                                                     const unsigned int* __restrict__ workList, const LayerPlan* __restrict__ layers,
                                                     const FieldState* __restrict__ st, FieldConst fc) {
     constexpr int TW = kSuperpTileX + 2 * kMaxSuperpR;   // 96
     constexpr int TH = kSuperpTileY + 2 * kMaxSuperpR;   // 72
-    constexpr int ES = kMaxSuperpR + 2;                  // table stride 34 (odd number of dwords would be 33; 34 keeps 8B alignment)
+    constexpr int ES = kMaxSuperpR + 1;                  // table stride 33 dwords: odd -> lanes hit distinct LDS banks
     __shared__ float tile[TW * TH];
     __shared__ float eTab[256 * ES];
     const int tid = threadIdx.y * blockDim.x + threadIdx.x;
@@ -515,14 +515,17 @@ __global__ __launch_bounds__(256) void k_superpose(const float* __restrict__ bev
         }
         __syncthreads();
         const int row = threadIdx.y, col = threadIdx.x;
+        // Conflict-free schedule of the reference (kernel_wrapper.cuh:468-476), valid for wave64: at a given i every
+        // thread (row, col) updates tile[row+i][col+j] — distinct elements for all 256 threads — and the lanes of one
+        // wave (two full rows) walk j in lockstep; a barrier separates successive i.
         for (int i = 0; i < 2 * rad + 1; ++i) {
             const float wi = dose * e[abs(rad - i)];
-            float* trow = tile + (row + i) * tw + col;
-            for (int j = 0; j < 2 * rad + 1; ++j) {
-                __hip_atomic_fetch_add(trow + j, wi * e[abs(rad - j)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
+            // volatile: lane c's update of column c+j must stay ordered after lane c+1's update of the same column at
+            // tap j-1 (same wave, lockstep) — the compiler may not batch loads of several taps ahead of the stores
+            volatile float* trow = tile + (row + i) * tw + col;
+            for (int j = 0; j < 2 * rad + 1; ++j) trow[j] = trow[j] + wi * e[abs(rad - j)];
+            __syncthreads();
         }
-        __syncthreads();
         // flush (kernel_wrapper.cuh:480-488): tile element (r, c) -> bev[k][by*8 + r + 32 - rad][bx*32 + c + 32 - rad]
         float* out = bevDose + (size_t)k * outSlice + (size_t)(by * kSuperpTileY + kMaxSuperpR - rad) * outPitch
                      + bx * kSuperpTileX + kMaxSuperpR - rad;
