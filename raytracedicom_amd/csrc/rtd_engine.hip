@@ -11,6 +11,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <limits>
@@ -55,7 +56,7 @@ struct rtd_field_impl {
     size_t R = 0;
     // device workspace
     float *dSpotWeights = nullptr, *dConvInterm = nullptr, *dRayWeights = nullptr;
-    float *dDensity = nullptr, *dWepl = nullptr, *dIdd = nullptr, *dRSigma = nullptr, *dBev = nullptr;
+    float *dDensity = nullptr, *dWepl = nullptr, *dIdd = nullptr, *dRSigma = nullptr, *dBev = nullptr, *dBevPart = nullptr;
     int *dFirstInside = nullptr, *dFirstOutside = nullptr, *dFirstPassive = nullptr, *dWeplMin = nullptr;
     unsigned char* dTileRad = nullptr;
     unsigned int* dWorkList = nullptr;
@@ -65,6 +66,7 @@ struct rtd_field_impl {
     hipEvent_t ev[8] = {};
     bool computed = false;
     int superpBlocks = 0;
+    int ksVariant = 2;   // 2 = output-stationary MFMA kernel; 1 = scatter kernel (kept for A/B profiling: RTD_KS_VARIANT=1)
 };
 
 #define RTD_HIP(h, call)                                                                         \
@@ -316,7 +318,7 @@ int rtd_field_destroy(rtd_handle hh, rtd_field ff) {
     if (!h || !f) return RTD_ERR_INVALID_ARG;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = { f->dSpotWeights, f->dConvInterm, f->dRayWeights, f->dDensity, f->dWepl, f->dIdd, f->dRSigma, f->dBev,
+    void* ptrs[] = { f->dSpotWeights, f->dConvInterm, f->dRayWeights, f->dDensity, f->dWepl, f->dIdd, f->dRSigma, f->dBev, f->dBevPart,
                      f->dFirstInside, f->dFirstOutside, f->dFirstPassive, f->dWeplMin, f->dTileRad, f->dWorkList,
                      f->dLayers, f->dState };
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -410,7 +412,7 @@ int rtd_field_create(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dims[
     int st = RTD_OK;
     auto A = [&](auto** p, size_t n) { if (st == RTD_OK) st = devAlloc(h, p, n); };
     A(&f->dSpotWeights, nSpot); A(&f->dConvInterm, (size_t)W * b->spot_ny * L); A(&f->dRayWeights, R * L);
-    A(&f->dDensity, R * S); A(&f->dWepl, R * S); A(&f->dIdd, R * S * L); A(&f->dRSigma, R * S * L); A(&f->dBev, P * S);
+    A(&f->dDensity, R * S); A(&f->dWepl, R * S); A(&f->dIdd, R * S * L); A(&f->dRSigma, R * S * L); A(&f->dBev, P * S); A(&f->dBevPart, P * S * kKsGroups);
     A(&f->dFirstInside, R); A(&f->dFirstOutside, R); A(&f->dFirstPassive, R * L); A(&f->dWeplMin, (size_t)S);
     A(&f->dTileRad, (size_t)L * S * tilesX * tilesY); A(&f->dWorkList, workCap); A(&f->dLayers, (size_t)L); A(&f->dState, (size_t)1);
     if (st != RTD_OK) { rtd_field_destroy(hh, reinterpret_cast<rtd_field>(f)); return st; }
@@ -423,6 +425,9 @@ int rtd_field_create(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dims[
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) nCu = prop.multiProcessorCount;
     f->superpBlocks = nCu * 2;
+    if (const char* v = std::getenv("RTD_KS_VARIANT")) f->ksVariant = std::atoi(v) == 1 ? 1 : 2;
+    e = hipMemset(f->dBev, 0, P * (size_t)S * sizeof(float));   // slices outside [entry, passive) are never written: keep them zero
+    if (e != hipSuccess) { h->error = std::string("HIP error: ") + hipGetErrorString(e); rtd_field_destroy(hh, reinterpret_cast<rtd_field>(f)); return RTD_ERR_HIP; }
     *out = reinterpret_cast<rtd_field>(f);
     return RTD_OK;
 }
@@ -447,7 +452,6 @@ int rtd_field_compute(rtd_handle hh, rtd_field ff, float* dev_dose) {
                                          fc.W, fc.H, f->dDensity, f->dWepl, f->dFirstInside, f->dFirstOutside, f->dWeplMin, f->dState);
     if (timing) RTD_HIP(h, hipEventRecord(f->ev[1], s));
     k_plan<<<1, 64, 0, s>>>(f->dState, f->dLayers, f->dWeplMin, fc);
-    RTD_HIP(h, hipMemsetAsync(f->dBev, 0, P * fc.S * sizeof(float), s));                       // fillDevMem, :824-827
     RTD_HIP(h, hipMemsetAsync(f->dTileRad, kNoRadius, (size_t)fc.L * fc.S * fc.tilesX * fc.tilesY, s));
     k_conv_x<<<dim3(fc.W / 32, (fc.spotNy + 7) / 8, fc.L), blk, 0, s>>>(f->dSpotWeights, f->dConvInterm, f->dLayers, f->dState, fc);
     k_conv_y<<<dim3(fc.W / 32, fc.H / 8, fc.L), blk, 0, s>>>(f->dConvInterm, f->dRayWeights, f->dLayers, f->dState, fc);
@@ -459,7 +463,15 @@ int rtd_field_compute(rtd_handle hh, rtd_field ff, float* dev_dose) {
     k_ks_plan<<<1, 64, 0, s>>>(f->dState, f->dLayers, fc, f->rayIdxToDoseIdx, f->transfer0, (int)f->doseDims[0], (int)f->doseDims[1],
                                (int)f->doseDims[2]);
     if (timing) RTD_HIP(h, hipEventRecord(f->ev[4], s));
-    k_superpose<<<f->superpBlocks, blk, 0, s>>>(f->dIdd, f->dRSigma, f->dBev, f->dTileRad, f->dWorkList, f->dLayers, f->dState, fc);
+    if (f->ksVariant == 1) {
+        RTD_HIP(h, hipMemsetAsync(f->dBev, 0, P * fc.S * sizeof(float), s));
+        k_superpose<<<f->superpBlocks, blk, 0, s>>>(f->dIdd, f->dRSigma, f->dBev, f->dTileRad, f->dWorkList, f->dLayers, f->dState, fc);
+    } else {
+        const int nTX = (fc.bevW + kKsTileX - 1) / kKsTileX, nTY = (fc.bevH + kKsTileY - 1) / kKsTileY;
+        const int nItems = fc.S * kKsGroups * nTY * nTX;
+        k_superpose_mfma<<<(nItems + 3) / 4, 256, 0, s>>>(f->dIdd, f->dRSigma, f->dBevPart, f->dTileRad, f->dLayers, f->dState, fc, nTX, nTY);
+        k_superpose_reduce<<<1024, 256, 0, s>>>(f->dBevPart, f->dBev, f->dState, fc);
+    }
     if (timing) RTD_HIP(h, hipEventRecord(f->ev[5], s));
     k_transfer<<<dim3((f->doseDims[0] + 31) / 32, (f->doseDims[1] + 7) / 8), blk, 0, s>>>(dev_dose, (int)f->doseDims[0], (int)f->doseDims[1],
                                                                                           (int)f->doseDims[2], f->dBev, f->dState, fc);

@@ -539,6 +539,187 @@ __global__ __launch_bounds__(256) void k_superpose(const float* __restrict__ bev
 }
 
 // ------------------------------------------------------------------------------------------------
+// K7 (v2): output-stationary kernel superposition on the matrix cores, one autonomous WAVE per work item.
+//
+// Same arithmetic as kernelSuperposition<rad> (kernel_wrapper.cuh:432-489): every source voxel s adds the
+// separable patch  dose_s * e_s[|dy|] * e_s[|dx|],  |dy|,|dx| <= rho_s  (rho_s = batch radius of its 32x8 tile,
+// e_s = erf-difference weights of ITS OWN 1/sigma). A patch is a rank-1 update, so a wave that OWNS a 32x64
+// tile of the padded BEV slice at step k accumulates  D += A * B  with
+//     A[r][s] = dose_s * m_s[r - y_s],   B[s][c] = m_s[c - x_s]      (m_s = mirrored weight table, 0 outside rho_s)
+// on v_mfma_f32_16x16x4_f32 (exact f32 FMA chain at the f32 vector rate; the 8 accumulator tiles have static
+// register indices while the operands are data, which a per-source-radius VALU loop cannot have).
+// Work item = (layer group g, step k, output tile): the wave walks the layers l = g, g+G, ... and, per layer,
+// the source rows in reach; a chunk of <= 64 sources of a row gets its weight tables built into the wave's
+// private LDS slice (one source per lane, erfDiffs of kernel_wrapper.cuh:459-467), then every (source quad,
+// 16x16 tile) pair whose bands intersect is one MFMA. No block barrier, no float atomics (the reference's
+// flush, kernel_wrapper.cuh:486), no zero-fill pass (kernel_wrapper.cu:824-827): each partial element is stored
+// once and k_superpose_reduce adds the G partials in fixed order, so the BEV dose is bitwise reproducible.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kKsTileX = 64, kKsTileY = 32;   // output tile owned by one wave (4 x 2 MFMA tiles)
+constexpr int kKsWaveLds = 2560;              // floats of LDS per wave (10 KiB): tables [CS][T] + doses [CS]
+constexpr int kKsGroups = 4;                  // layer groups = partial BEV buffers
+
+__device__ inline int clampI(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__global__ __launch_bounds__(256, 4) void k_superpose_mfma(const float* __restrict__ bevIdd, const float* __restrict__ bevRSigmaEff,
+                                                            float* __restrict__ bevPart, const unsigned char* __restrict__ tileRad,
+                                                            const LayerPlan* __restrict__ layers, const FieldState* __restrict__ st,
+                                                            FieldConst fc, int nTX, int nTY) {
+    __shared__ float ldsAll[4 * kKsWaveLds];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* lds = ldsAll + wave * kKsWaveLds;
+    // decode the work item (wave-uniform): fastest index = tile x, then tile y, then group, then step
+    int item = blockIdx.x * 4 + wave;
+    const int tX = item % nTX; item /= nTX;
+    const int tY = item % nTY; item /= nTY;
+    const int g = item % kKsGroups;
+    const int k = item / kKsGroups;
+    const int first = st->beamFirstInside, calcPassive = st->firstCalculatedPassive;
+    if (k >= fc.S || k < first || k >= calcPassive) return;
+    const int li = lane & 15, kq = lane >> 4;                         // MFMA 16x16x4: A[i=li][k=kq], B[k=kq][j=li]
+    const int ox0 = tX * kKsTileX, oy0 = tY * kKsTileY;               // padded BEV coordinates of the owned tile
+    const int W = fc.W, H = fc.H;
+    const size_t memStep = (size_t)W * H;
+    const int nTiles = fc.tilesX * fc.tilesY;
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+
+    for (int layer = g; layer < fc.L; layer += kKsGroups) {
+        if (k >= layers[layer].layerFirstPassive) continue;          // nothing deposited by this layer at this step
+        const int* eff = layers[layer].effRad;
+        const unsigned char* tr = tileRad + ((size_t)layer * fc.S + k) * nTiles;
+        // ---- reach: largest batch radius among the 32x8 source tiles whose patches can touch the owned tile ----
+        int rho = -1;
+        {
+            // source-coordinate rectangle of the owned tile: [ox0-32, ox0+31] x [oy0-32, oy0-1]
+            const int tx0 = clampI((ox0 - 32 - kMaxSuperpR) >> 5, 0, fc.tilesX - 1), tx1 = clampI((ox0 + 31 + kMaxSuperpR) >> 5, 0, fc.tilesX - 1);
+            const int ty0 = clampI((oy0 - 32 - kMaxSuperpR) >> 3, 0, fc.tilesY - 1), ty1 = clampI((oy0 - 1 + kMaxSuperpR) >> 3, 0, fc.tilesY - 1);
+            const int ntx = tx1 - tx0 + 1, nt = ntx * (ty1 - ty0 + 1);
+            for (int t = lane; t < nt; t += kWave) {
+                const int tx = tx0 + t % ntx, ty = ty0 + t / ntx;
+                const int own = tr[ty * fc.tilesX + tx];
+                if (own > kMaxSuperpR) continue;                     // unclassified (0xFF) or overflow (reported via errorFlags)
+                const int r = eff[own];
+                const int gx = max(max(tx * 32 - (ox0 + 31), (ox0 - 32) - (tx * 32 + 31)), 0);
+                const int gy = max(max(ty * 8 - (oy0 - 1), (oy0 - 32) - (ty * 8 + 7)), 0);
+                if (max(gx, gy) <= r) rho = max(rho, r);
+            }
+            rho = waveMaxI(rho);
+        }
+        if (rho < 0) continue;                                       // wave-uniform
+        const int Tm = rho + 1, T = 2 * Tm + 1;                      // mirrored table m[u], u = d + Tm, d in [-Tm, Tm]; m[+-Tm] = 0
+        const int cx0 = max(ox0 - 32 - rho, 0), cx1 = min(ox0 + 31 + rho + 1, W);
+        const int ry0 = max(oy0 - 32 - rho, 0), ry1 = min(oy0 - 1 + rho + 1, H);
+        if (cx1 <= cx0 || ry1 <= ry0) continue;
+        const int CS = min(kWave, (kKsWaveLds / (T + 1)) & ~3);      // sources per chunk (whole quads)
+        float* dArr = lds + CS * T;
+        const size_t sliceOff = (size_t)layer * memStep * fc.S + (size_t)k * memStep;
+
+        for (int sy = ry0; sy < ry1; ++sy) {
+            const int psy = sy + 32;                                 // padded y of this source row
+            const bool ya0 = (oy0 <= psy + rho) && (oy0 + 15 >= psy - rho);
+            const bool ya1 = (oy0 + 16 <= psy + rho) && (oy0 + 31 >= psy - rho);
+            for (int c0 = cx0; c0 < cx1; c0 += CS) {
+                // ---- build: weight table of one source per lane ----
+                __builtin_amdgcn_wave_barrier();
+                if (lane < CS) {
+                    const int sx = c0 + lane;
+                    float dose = 0.0f, rs = 0.0f;
+                    int rhoS = -1;
+                    if (sx < cx1) {
+                        const size_t gi = sliceOff + (size_t)sy * W + sx;
+                        dose = bevIdd[gi];
+                        if (dose != 0.0f) {
+                            rs = bevRSigmaEff[gi];
+                            const int own = tr[(sy >> 3) * fc.tilesX + (sx >> 5)];
+                            rhoS = own <= kMaxSuperpR ? eff[own] : -1;
+                            if (rhoS < 0) dose = 0.0f;
+                        }
+                    }
+                    dArr[lane] = dose;
+                    float* m = lds + lane * T;
+                    float erfNew = 0.0f, erfOld = 0.0f;
+                    if (rhoS >= 0) { erfNew = erff(rs * 0.5f); erfOld = -erfNew; }
+                    for (int i = 0; i <= Tm; ++i) {
+                        float e = 0.0f;
+                        if (i <= rhoS) {
+                            e = 0.5f * (erfNew - erfOld);
+                            erfOld = erfNew;
+                            erfNew = erff(rs * ((float)i + 1.5f));
+                        }
+                        m[Tm + i] = e;
+                        m[Tm - i] = e;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // ---- accumulate: one MFMA per (source quad, 16x16 output tile) pair whose bands intersect ----
+                const int nq = (min(CS, cx1 - c0) + 3) >> 2;
+                for (int q = 0; q < nq; ++q) {
+                    const int src = 4 * q + kq;
+                    const float dl = dArr[src];
+                    if (!__any(dl != 0.0f)) continue;                // quad carries no dose: contributes exact zeros
+                    const float* m = lds + src * T + Tm;
+                    const int psx0 = c0 + 4 * q + 32;                // padded x of the quad's first source
+                    const float a0 = dl * m[clampI(oy0 + li - psy, -Tm, Tm)];
+                    const float a1 = dl * m[clampI(oy0 + 16 + li - psy, -Tm, Tm)];
+                    float b[4];
+                    bool xb[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int x0 = ox0 + 16 * t;
+                        xb[t] = (x0 <= psx0 + 3 + rho) && (x0 + 15 >= psx0 - rho);
+                        b[t] = m[clampI(x0 + li - psx0 - kq, -Tm, Tm)];
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        if (!xb[t]) continue;
+                        if (ya0) acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[t], acc[0][t], 0, 0, 0);
+                        if (ya1) acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[t], acc[1][t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // ---- epilogue: one plain store per partial element; D[row=(lane>>4)*4+reg][col=lane&15] ----
+    float* out = bevPart + ((size_t)g * fc.S + k) * fc.bevW * fc.bevH;
+#pragma unroll
+    for (int ty = 0; ty < 2; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < 4; ++tx)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int oy = oy0 + 16 * ty + 4 * kq + reg, ox = ox0 + 16 * tx + li;
+                if (oy < fc.bevH && ox < fc.bevW) out[(size_t)oy * fc.bevW + ox] = acc[ty][tx][reg];
+            }
+}
+
+// K7b: BEV dose = sum of the layer-group partials in fixed order (slices outside [entry, passive) are not touched).
+__global__ __launch_bounds__(256) void k_superpose_reduce(const float* __restrict__ bevPart, float* __restrict__ bevDose,
+                                                           const FieldState* __restrict__ st, FieldConst fc) {
+    const int first = st->beamFirstInside, calcPassive = st->firstCalculatedPassive;
+    const size_t P = (size_t)fc.bevW * fc.bevH;
+    const size_t n4 = (size_t)(calcPassive > first ? calcPassive - first : 0) * P / 4;   // P is a multiple of 4 (bevW % 32 == 0)
+    const float4* p0 = reinterpret_cast<const float4*>(bevPart + (size_t)first * P);
+    float4* o = reinterpret_cast<float4*>(bevDose + (size_t)first * P);
+    const size_t gstride = (size_t)fc.S * P / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 a = p0[i];
+#pragma unroll
+        for (int gI = 1; gI < kKsGroups; ++gI) {
+            const float4 b = p0[i + gI * gstride];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        o[i] = a;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K8: fan -> dose-grid transfer = primTransfDiv (kernel_wrapper.cu:69-97). The reference copies the BEV slab
 // into a 3-D texture first (:1107-1141); here the trilinear BORDER sample is taken from the BEV buffer itself
 // (slab origin and extent applied in index arithmetic), which removes that copy. One thread per dose (x,y)
