@@ -66,6 +66,7 @@ struct rtd_field_impl {
     hipEvent_t ev[8] = {};
     bool computed = false;
     int superpBlocks = 0;
+    int ksGroups = 10;   // layer groups of the superposition (partial BEV buffers); RTD_KS_GROUPS overrides
     int ksVariant = 2;   // 2 = output-stationary MFMA kernel; 1 = scatter kernel (kept for A/B profiling: RTD_KS_VARIANT=1)
 };
 
@@ -404,6 +405,8 @@ int rtd_field_create(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dims[
         for (int i = 0; i < kMaxSuperpR + 2; ++i) p.effRad[i] = i;
     }
 
+    if (const char* v = std::getenv("RTD_KS_GROUPS")) f->ksGroups = std::max(1, std::min(kKsMaxGroups, std::atoi(v)));
+    f->ksGroups = std::min(f->ksGroups, L);
     // workspace (the reference's per-beam cudaMallocs, :685-734, :804-808)
     const size_t R = f->R, P = (size_t)fc.bevW * fc.bevH;
     const size_t nSpot = (size_t)b->spot_nx * b->spot_ny * L;
@@ -412,7 +415,7 @@ int rtd_field_create(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dims[
     int st = RTD_OK;
     auto A = [&](auto** p, size_t n) { if (st == RTD_OK) st = devAlloc(h, p, n); };
     A(&f->dSpotWeights, nSpot); A(&f->dConvInterm, (size_t)W * b->spot_ny * L); A(&f->dRayWeights, R * L);
-    A(&f->dDensity, R * S); A(&f->dWepl, R * S); A(&f->dIdd, R * S * L); A(&f->dRSigma, R * S * L); A(&f->dBev, P * S); A(&f->dBevPart, P * S * kKsGroups);
+    A(&f->dDensity, R * S); A(&f->dWepl, R * S); A(&f->dIdd, R * S * L); A(&f->dRSigma, R * S * L); A(&f->dBev, P * S); A(&f->dBevPart, P * S * f->ksGroups);
     A(&f->dFirstInside, R); A(&f->dFirstOutside, R); A(&f->dFirstPassive, R * L); A(&f->dWeplMin, (size_t)S);
     A(&f->dTileRad, (size_t)L * S * tilesX * tilesY); A(&f->dWorkList, workCap); A(&f->dLayers, (size_t)L); A(&f->dState, (size_t)1);
     if (st != RTD_OK) { rtd_field_destroy(hh, reinterpret_cast<rtd_field>(f)); return st; }
@@ -468,9 +471,10 @@ int rtd_field_compute(rtd_handle hh, rtd_field ff, float* dev_dose) {
         k_superpose<<<f->superpBlocks, blk, 0, s>>>(f->dIdd, f->dRSigma, f->dBev, f->dTileRad, f->dWorkList, f->dLayers, f->dState, fc);
     } else {
         const int nTX = (fc.bevW + kKsTileX - 1) / kKsTileX, nTY = (fc.bevH + kKsTileY - 1) / kKsTileY;
-        const int nItems = fc.S * kKsGroups * nTY * nTX;
-        k_superpose_mfma<<<(nItems + 3) / 4, 256, 0, s>>>(f->dIdd, f->dRSigma, f->dBevPart, f->dTileRad, f->dLayers, f->dState, fc, nTX, nTY);
-        k_superpose_reduce<<<1024, 256, 0, s>>>(f->dBevPart, f->dBev, f->dState, fc);
+        const int G = f->ksGroups;
+        const int nItems = fc.S * G * nTY * nTX;
+        k_superpose_mfma<<<(nItems + 3) / 4, 256, 0, s>>>(f->dIdd, f->dRSigma, f->dBevPart, f->dTileRad, f->dLayers, f->dState, fc, nTX, nTY, G);
+        k_superpose_reduce<<<1024, 256, 0, s>>>(f->dBevPart, f->dBev, f->dState, fc, G);
     }
     if (timing) RTD_HIP(h, hipEventRecord(f->ev[5], s));
     k_transfer<<<dim3((f->doseDims[0] + 31) / 32, (f->doseDims[1] + 7) / 8), blk, 0, s>>>(dev_dose, (int)f->doseDims[0], (int)f->doseDims[1],

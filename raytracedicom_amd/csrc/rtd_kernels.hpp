@@ -557,14 +557,14 @@ __global__ __launch_bounds__(256) void k_superpose(const float* __restrict__ bev
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kKsTileX = 64, kKsTileY = 32;   // output tile owned by one wave (4 x 2 MFMA tiles)
 constexpr int kKsWaveLds = 2560;              // floats of LDS per wave (10 KiB): tables [CS][T] + doses [CS]
-constexpr int kKsGroups = 4;                  // layer groups = partial BEV buffers
+constexpr int kKsMaxGroups = 32;              // upper bound of layer groups (= partial BEV buffers)
 
 __device__ inline int clampI(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 __global__ __launch_bounds__(256, 4) void k_superpose_mfma(const float* __restrict__ bevIdd, const float* __restrict__ bevRSigmaEff,
                                                             float* __restrict__ bevPart, const unsigned char* __restrict__ tileRad,
                                                             const LayerPlan* __restrict__ layers, const FieldState* __restrict__ st,
-                                                            FieldConst fc, int nTX, int nTY) {
+                                                            FieldConst fc, int nTX, int nTY, int G) {
     __shared__ float ldsAll[4 * kKsWaveLds];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float* lds = ldsAll + wave * kKsWaveLds;
@@ -572,10 +572,10 @@ __global__ __launch_bounds__(256, 4) void k_superpose_mfma(const float* __restri
     int item = blockIdx.x * 4 + wave;
     const int tX = item % nTX; item /= nTX;
     const int tY = item % nTY; item /= nTY;
-    const int g = item % kKsGroups;
-    const int k = item / kKsGroups;
+    const int g = item % G;
+    const int k = fc.S - 1 - item / G;                                // deepest steps (largest radii, most work) are dispatched first
     const int first = st->beamFirstInside, calcPassive = st->firstCalculatedPassive;
-    if (k >= fc.S || k < first || k >= calcPassive) return;
+    if (k < 0 || k < first || k >= calcPassive) return;
     const int li = lane & 15, kq = lane >> 4;                         // MFMA 16x16x4: A[i=li][k=kq], B[k=kq][j=li]
     const int ox0 = tX * kKsTileX, oy0 = tY * kKsTileY;               // padded BEV coordinates of the owned tile
     const int W = fc.W, H = fc.H;
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(256, 4) void k_superpose_mfma(const float* __restri
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
-    for (int layer = g; layer < fc.L; layer += kKsGroups) {
+    for (int layer = g; layer < fc.L; layer += G) {
         if (k >= layers[layer].layerFirstPassive) continue;          // nothing deposited by this layer at this step
         const int* eff = layers[layer].effRad;
         const unsigned char* tr = tileRad + ((size_t)layer * fc.S + k) * nTiles;
@@ -619,68 +619,72 @@ __global__ __launch_bounds__(256, 4) void k_superpose_mfma(const float* __restri
         float* dArr = lds + CS * T;
         const size_t sliceOff = (size_t)layer * memStep * fc.S + (size_t)k * memStep;
 
-        for (int sy = ry0; sy < ry1; ++sy) {
-            const int psy = sy + 32;                                 // padded y of this source row
-            const bool ya0 = (oy0 <= psy + rho) && (oy0 + 15 >= psy - rho);
-            const bool ya1 = (oy0 + 16 <= psy + rho) && (oy0 + 31 >= psy - rho);
-            for (int c0 = cx0; c0 < cx1; c0 += CS) {
-                // ---- build: weight table of one source per lane ----
-                __builtin_amdgcn_wave_barrier();
-                if (lane < CS) {
-                    const int sx = c0 + lane;
-                    float dose = 0.0f, rs = 0.0f;
-                    int rhoS = -1;
-                    if (sx < cx1) {
-                        const size_t gi = sliceOff + (size_t)sy * W + sx;
-                        dose = bevIdd[gi];
-                        if (dose != 0.0f) {
-                            rs = bevRSigmaEff[gi];
-                            const int own = tr[(sy >> 3) * fc.tilesX + (sx >> 5)];
-                            rhoS = own <= kMaxSuperpR ? eff[own] : -1;
-                            if (rhoS < 0) dose = 0.0f;
-                        }
-                    }
-                    dArr[lane] = dose;
-                    float* m = lds + lane * T;
-                    float erfNew = 0.0f, erfOld = 0.0f;
-                    if (rhoS >= 0) { erfNew = erff(rs * 0.5f); erfOld = -erfNew; }
-                    for (int i = 0; i <= Tm; ++i) {
-                        float e = 0.0f;
-                        if (i <= rhoS) {
-                            e = 0.5f * (erfNew - erfOld);
-                            erfOld = erfNew;
-                            erfNew = erff(rs * ((float)i + 1.5f));
-                        }
-                        m[Tm + i] = e;
-                        m[Tm - i] = e;
-                    }
+        // The window's sources are walked row-major in chunks of CS (rows padded to whole quads), so a chunk may
+        // span several source rows and every lane builds one table.
+        const int nCols = ((cx1 - cx0 + 3) >> 2) << 2;
+        const int nSrc = (ry1 - ry0) * nCols;
+        for (int s0 = 0; s0 < nSrc; s0 += CS) {
+            // ---- build: weight table of one source per lane ----
+            float dose = 0.0f;
+            int sIdx = s0 + lane, sy = 0, sx = 0;
+            const bool inChunk = lane < CS && sIdx < nSrc;
+            if (inChunk) {
+                const int r = sIdx / nCols;
+                sy = ry0 + r; sx = cx0 + (sIdx - r * nCols);
+                if (sx < cx1) dose = bevIdd[sliceOff + (size_t)sy * W + sx];
+            }
+            if (!__any(dose != 0.0f)) continue;                      // chunk carries no dose: contributes exact zeros
+            __builtin_amdgcn_wave_barrier();
+            if (lane < CS) {
+                float rs = 0.0f;
+                int rhoS = -1;
+                if (dose != 0.0f) {
+                    rs = bevRSigmaEff[sliceOff + (size_t)sy * W + sx];
+                    const int own = tr[(sy >> 3) * fc.tilesX + (sx >> 5)];
+                    rhoS = own <= kMaxSuperpR ? eff[own] : -1;
+                    if (rhoS < 0) dose = 0.0f;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                // ---- accumulate: one MFMA per (source quad, 16x16 output tile) pair whose bands intersect ----
-                const int nq = (min(CS, cx1 - c0) + 3) >> 2;
-                for (int q = 0; q < nq; ++q) {
-                    const int src = 4 * q + kq;
-                    const float dl = dArr[src];
-                    if (!__any(dl != 0.0f)) continue;                // quad carries no dose: contributes exact zeros
-                    const float* m = lds + src * T + Tm;
-                    const int psx0 = c0 + 4 * q + 32;                // padded x of the quad's first source
-                    const float a0 = dl * m[clampI(oy0 + li - psy, -Tm, Tm)];
-                    const float a1 = dl * m[clampI(oy0 + 16 + li - psy, -Tm, Tm)];
-                    float b[4];
-                    bool xb[4];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int x0 = ox0 + 16 * t;
-                        xb[t] = (x0 <= psx0 + 3 + rho) && (x0 + 15 >= psx0 - rho);
-                        b[t] = m[clampI(x0 + li - psx0 - kq, -Tm, Tm)];
+                dArr[lane] = dose;
+                float* m = lds + lane * T;
+                float erfNew = 0.0f, erfOld = 0.0f;
+                if (rhoS >= 0) { erfNew = erff(rs * 0.5f); erfOld = -erfNew; }
+                for (int i = 0; i <= Tm; ++i) {
+                    float e = 0.0f;
+                    if (i <= rhoS) {
+                        e = 0.5f * (erfNew - erfOld);
+                        erfOld = erfNew;
+                        erfNew = erff(rs * ((float)i + 1.5f));
                     }
+                    m[Tm + i] = e;
+                    m[Tm - i] = e;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ---- accumulate: one MFMA per (source quad, 16x16 output tile) pair whose bands intersect ----
+            const int nq = (min(CS, nSrc - s0) + 3) >> 2;
+            const int r0 = s0 / nCols;
+            int qRow = ry0 + r0, qCol = s0 - r0 * nCols;             // wave-uniform position of the current quad
+            const float* mq = lds + kq * T + Tm;                     // lane's source of quad 0
+            const int liA = oy0 + li - 32, liB = li - kq - 32 - cx0; // lane constants of the A / B table indices
+            for (int q = 0; q < nq; ++q, qCol += 4, mq += 4 * T) {
+                if (qCol >= nCols) { qCol = 0; ++qRow; }
+                const float dl = dArr[4 * q + kq];
+                if (!__any(dl != 0.0f)) continue;                    // quad carries no dose
+                const int psy = qRow + 32, psx0 = cx0 + qCol + 32;   // padded coordinates of the quad's first source
+                const bool ya0 = (oy0 <= psy + rho) && (oy0 + 15 >= psy - rho);
+                const bool ya1 = (oy0 + 16 <= psy + rho) && (oy0 + 31 >= psy - rho);
+                float a0 = 0.0f, a1 = 0.0f;
+                if (ya0) a0 = dl * mq[clampI(liA - qRow, -Tm, Tm)];
+                if (ya1) a1 = dl * mq[clampI(liA + 16 - qRow, -Tm, Tm)];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        if (!xb[t]) continue;
-                        if (ya0) acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[t], acc[0][t], 0, 0, 0);
-                        if (ya1) acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[t], acc[1][t], 0, 0, 0);
+                for (int t = 0; t < 4; ++t) {
+                    const int x0 = ox0 + 16 * t;
+                    if ((x0 <= psx0 + 3 + rho) && (x0 + 15 >= psx0 - rho)) {
+                        const float b = mq[clampI(x0 + liB - qCol, -Tm, Tm)];
+                        if (ya0) acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[0][t], 0, 0, 0);
+                        if (ya1) acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[1][t], 0, 0, 0);
                     }
                 }
             }
@@ -701,7 +705,7 @@ __global__ __launch_bounds__(256, 4) void k_superpose_mfma(const float* __restri
 
 // K7b: BEV dose = sum of the layer-group partials in fixed order (slices outside [entry, passive) are not touched).
 __global__ __launch_bounds__(256) void k_superpose_reduce(const float* __restrict__ bevPart, float* __restrict__ bevDose,
-                                                           const FieldState* __restrict__ st, FieldConst fc) {
+                                                           const FieldState* __restrict__ st, FieldConst fc, int G) {
     const int first = st->beamFirstInside, calcPassive = st->firstCalculatedPassive;
     const size_t P = (size_t)fc.bevW * fc.bevH;
     const size_t n4 = (size_t)(calcPassive > first ? calcPassive - first : 0) * P / 4;   // P is a multiple of 4 (bevW % 32 == 0)
@@ -710,8 +714,7 @@ __global__ __launch_bounds__(256) void k_superpose_reduce(const float* __restric
     const size_t gstride = (size_t)fc.S * P / 4;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float4 a = p0[i];
-#pragma unroll
-        for (int gI = 1; gI < kKsGroups; ++gI) {
+        for (int gI = 1; gI < G; ++gI) {
             const float4 b = p0[i + gI * gstride];
             a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
         }
