@@ -59,15 +59,12 @@ struct rtd_field_impl {
     float *dDensity = nullptr, *dWepl = nullptr, *dIdd = nullptr, *dRSigma = nullptr, *dBev = nullptr, *dBevPart = nullptr;
     int *dFirstInside = nullptr, *dFirstOutside = nullptr, *dFirstPassive = nullptr, *dWeplMin = nullptr;
     unsigned char* dTileRad = nullptr;
-    unsigned int* dWorkList = nullptr;
     LayerPlan* dLayers = nullptr;
     FieldState* dState = nullptr;
     std::vector<LayerPlan> hLayers;
     hipEvent_t ev[8] = {};
     bool computed = false;
-    int superpBlocks = 0;
     int ksGroups = 10;   // layer groups of the superposition (partial BEV buffers); RTD_KS_GROUPS overrides
-    int ksVariant = 2;   // 2 = output-stationary MFMA kernel; 1 = scatter kernel (kept for A/B profiling: RTD_KS_VARIANT=1)
 };
 
 #define RTD_HIP(h, call)                                                                         \
@@ -320,7 +317,7 @@ int rtd_field_destroy(rtd_handle hh, rtd_field ff) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = { f->dSpotWeights, f->dConvInterm, f->dRayWeights, f->dDensity, f->dWepl, f->dIdd, f->dRSigma, f->dBev, f->dBevPart,
-                     f->dFirstInside, f->dFirstOutside, f->dFirstPassive, f->dWeplMin, f->dTileRad, f->dWorkList,
+                     f->dFirstInside, f->dFirstOutside, f->dFirstPassive, f->dWeplMin, f->dTileRad,
                      f->dLayers, f->dState };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : f->ev) if (e) (void)hipEventDestroy(e);
@@ -357,8 +354,8 @@ int rtd_field_create(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dims[
     const int W = roundTo(rSteps - lSteps + 1, kSuperpTileX), H = roundTo(tSteps - bSteps + 1, kSuperpTileY);   // :659
     if (W <= 0 || H <= 0) return fail(h, RTD_ERR_INVALID_ARG, "rtd_field_create: empty ray grid");
     const int tilesX = W / kSuperpTileX, tilesY = H / kSuperpTileY;
-    if (L > kMaxLayers || S > kMaxSteps || tilesX * tilesY > kMaxTiles)
-        return fail(h, RTD_ERR_INVALID_ARG, "rtd_field_create: more than 256 layers, 4096 steps or 4096 ray tiles");
+    if (L > kMaxLayers || S > kMaxSteps)
+        return fail(h, RTD_ERR_INVALID_ARG, "rtd_field_create: more than 256 layers or 4096 steps");
 
     auto* f = new rtd_field_impl();
     FieldConst& fc = f->fc;
@@ -410,25 +407,18 @@ int rtd_field_create(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dims[
     // workspace (the reference's per-beam cudaMallocs, :685-734, :804-808)
     const size_t R = f->R, P = (size_t)fc.bevW * fc.bevH;
     const size_t nSpot = (size_t)b->spot_nx * b->spot_ny * L;
-    const size_t workCap = (size_t)L * S * tilesX * tilesY;
-    fc.workCapacity = (unsigned int)std::min<size_t>(workCap, 0xFFFFFFFFull);
     int st = RTD_OK;
     auto A = [&](auto** p, size_t n) { if (st == RTD_OK) st = devAlloc(h, p, n); };
     A(&f->dSpotWeights, nSpot); A(&f->dConvInterm, (size_t)W * b->spot_ny * L); A(&f->dRayWeights, R * L);
     A(&f->dDensity, R * S); A(&f->dWepl, R * S); A(&f->dIdd, R * S * L); A(&f->dRSigma, R * S * L); A(&f->dBev, P * S); A(&f->dBevPart, P * S * f->ksGroups);
     A(&f->dFirstInside, R); A(&f->dFirstOutside, R); A(&f->dFirstPassive, R * L); A(&f->dWeplMin, (size_t)S);
-    A(&f->dTileRad, (size_t)L * S * tilesX * tilesY); A(&f->dWorkList, workCap); A(&f->dLayers, (size_t)L); A(&f->dState, (size_t)1);
+    A(&f->dTileRad, (size_t)L * S * tilesX * tilesY); A(&f->dLayers, (size_t)L); A(&f->dState, (size_t)1);
     if (st != RTD_OK) { rtd_field_destroy(hh, reinterpret_cast<rtd_field>(f)); return st; }
     hipError_t e = hipMemcpy(f->dSpotWeights, b->spot_weights, nSpot * sizeof(float), hipMemcpyHostToDevice);   // :851
     if (e == hipSuccess) e = hipMemcpy(f->dLayers, f->hLayers.data(), (size_t)L * sizeof(LayerPlan), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(f->dState, 0, sizeof(FieldState));
     for (auto& ev : f->ev) if (e == hipSuccess) e = hipEventCreate(&ev);
     if (e != hipSuccess) { h->error = std::string("HIP error: ") + hipGetErrorString(e); rtd_field_destroy(hh, reinterpret_cast<rtd_field>(f)); return RTD_ERR_HIP; }
-    int nCu = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) nCu = prop.multiProcessorCount;
-    f->superpBlocks = nCu * 2;
-    if (const char* v = std::getenv("RTD_KS_VARIANT")) f->ksVariant = std::atoi(v) == 1 ? 1 : 2;
     e = hipMemset(f->dBev, 0, P * (size_t)S * sizeof(float));   // slices outside [entry, passive) are never written: keep them zero
     if (e != hipSuccess) { h->error = std::string("HIP error: ") + hipGetErrorString(e); rtd_field_destroy(hh, reinterpret_cast<rtd_field>(f)); return RTD_ERR_HIP; }
     *out = reinterpret_cast<rtd_field>(f);
@@ -446,30 +436,37 @@ int rtd_field_compute(rtd_handle hh, rtd_field ff, float* dev_dose) {
     const bool timing = h->opt.fine_grained_timing != 0;
     const dim3 blk(kSuperpTileX, kSuperpTileY);
     const dim3 rayGrid(fc.W / kSuperpTileX, fc.H / kSuperpTileY);
-    const size_t P = (size_t)fc.bevW * fc.bevH;
 
     RTD_HIP(h, hipEventRecord(f->ev[0], s));
-    k_reset<<<4, 256, 0, s>>>(f->dState, f->dLayers, fc.L, f->dWeplMin, fc.S);
+    k_reset<<<1, 256, 0, s>>>(f->dState, f->dLayers, fc.L);
     const size_t lutLds = (size_t)(h->lut.nDensity + h->lut.nSp) * sizeof(float);
-    k_trace<<<rayGrid, blk, lutLds, s>>>(h->dCt, (int)h->ctDims[0], (int)h->ctDims[1], (int)h->ctDims[2], h->lut, f->tracer,
-                                         fc.W, fc.H, f->dDensity, f->dWepl, f->dFirstInside, f->dFirstOutside, f->dWeplMin, f->dState);
+    // dIdd doubles as the HU scratch of the tracer (it is written by k_fill only afterwards)
+    k_trace_sample<<<dim3((unsigned)(f->R / 256), (fc.S + kTraceSeg - 1) / kTraceSeg), 256, lutLds, s>>>(
+        h->dCt, (int)h->ctDims[0], (int)h->ctDims[1], (int)h->ctDims[2], h->lut, f->tracer, fc.W, fc.H, f->dDensity, f->dWepl, f->dIdd);
+    k_trace_scan<<<(unsigned)(f->R / 64), 64, 0, s>>>(f->dIdd, f->dWepl, fc.W, fc.H, (unsigned)fc.S, f->dFirstInside, f->dFirstOutside,
+                                                     f->dState);
+    k_slice_min<<<fc.S, 256, 0, s>>>(f->dWepl, f->R, f->dWeplMin);
     if (timing) RTD_HIP(h, hipEventRecord(f->ev[1], s));
     k_plan<<<1, 64, 0, s>>>(f->dState, f->dLayers, f->dWeplMin, fc);
     RTD_HIP(h, hipMemsetAsync(f->dTileRad, kNoRadius, (size_t)fc.L * fc.S * fc.tilesX * fc.tilesY, s));
     k_conv_x<<<dim3(fc.W / 32, (fc.spotNy + 7) / 8, fc.L), blk, 0, s>>>(f->dSpotWeights, f->dConvInterm, f->dLayers, f->dState, fc);
     k_conv_y<<<dim3(fc.W / 32, fc.H / 8, fc.L), blk, 0, s>>>(f->dConvInterm, f->dRayWeights, f->dLayers, f->dState, fc);
     if (timing) RTD_HIP(h, hipEventRecord(f->ev[2], s));
-    k_fill<<<dim3(rayGrid.x, rayGrid.y, fc.L), blk, 0, s>>>(f->dDensity, f->dWepl, f->dIdd, f->dRSigma, f->dRayWeights, f->dFirstInside,
-                                                            f->dFirstOutside, f->dFirstPassive, f->dTileRad, f->dWorkList, f->dLayers,
-                                                            f->dState, h->lut, f->fillGeom, fc);
+    {
+        const size_t fillLds = (size_t)(2 * h->lut.nSamples + h->lut.nRrl) * sizeof(float);
+        const dim3 fillGrid(rayGrid.x, rayGrid.y, fc.L);
+        if (fillLds <= 96 * 1024)
+            k_fill<true><<<fillGrid, blk, fillLds, s>>>(f->dDensity, f->dWepl, f->dIdd, f->dRSigma, f->dRayWeights, f->dFirstInside, f->dFirstOutside,
+                                                        f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc);
+        else
+            k_fill<false><<<fillGrid, blk, 0, s>>>(f->dDensity, f->dWepl, f->dIdd, f->dRSigma, f->dRayWeights, f->dFirstInside, f->dFirstOutside,
+                                                   f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc);
+    }
     if (timing) RTD_HIP(h, hipEventRecord(f->ev[3], s));
     k_ks_plan<<<1, 64, 0, s>>>(f->dState, f->dLayers, fc, f->rayIdxToDoseIdx, f->transfer0, (int)f->doseDims[0], (int)f->doseDims[1],
                                (int)f->doseDims[2]);
     if (timing) RTD_HIP(h, hipEventRecord(f->ev[4], s));
-    if (f->ksVariant == 1) {
-        RTD_HIP(h, hipMemsetAsync(f->dBev, 0, P * fc.S * sizeof(float), s));
-        k_superpose<<<f->superpBlocks, blk, 0, s>>>(f->dIdd, f->dRSigma, f->dBev, f->dTileRad, f->dWorkList, f->dLayers, f->dState, fc);
-    } else {
+    {
         const int nTX = (fc.bevW + kKsTileX - 1) / kKsTileX, nTY = (fc.bevH + kKsTileY - 1) / kKsTileY;
         const int G = f->ksGroups;
         const int nItems = fc.S * G * nTY * nTX;
@@ -477,8 +474,9 @@ int rtd_field_compute(rtd_handle hh, rtd_field ff, float* dev_dose) {
         k_superpose_reduce<<<1024, 256, 0, s>>>(f->dBevPart, f->dBev, f->dState, fc, G);
     }
     if (timing) RTD_HIP(h, hipEventRecord(f->ev[5], s));
-    k_transfer<<<dim3((f->doseDims[0] + 31) / 32, (f->doseDims[1] + 7) / 8), blk, 0, s>>>(dev_dose, (int)f->doseDims[0], (int)f->doseDims[1],
-                                                                                          (int)f->doseDims[2], f->dBev, f->dState, fc);
+    const int zChunk = 16;
+    k_transfer<<<dim3((f->doseDims[0] + 31) / 32, (f->doseDims[1] + 7) / 8, (f->doseDims[2] + zChunk - 1) / zChunk), blk, 0, s>>>(
+        dev_dose, (int)f->doseDims[0], (int)f->doseDims[1], (int)f->doseDims[2], f->dBev, f->dState, fc, zChunk);
     RTD_HIP(h, hipEventRecord(f->ev[6], s));
     RTD_HIP(h, hipGetLastError());
     f->computed = true;
@@ -518,7 +516,6 @@ int rtd_field_finish(rtd_handle hh, rtd_field ff, rtd_timing* timing, rtd_field_
     }
     if (st.errorFlags & kErrRadiusOverflow)
         return fail(h, RTD_ERR_RADIUS_OVERFLOW, "Found larger than allowed kernel superposition radius");   // kernel_wrapper.cu:965
-    if (st.errorFlags & kErrWorkOverflow) return fail(h, RTD_ERR_HIP, "superposition work list overflow");
     return RTD_OK;
 }
 

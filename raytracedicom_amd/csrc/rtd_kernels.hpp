@@ -16,10 +16,9 @@ namespace rtd {
 constexpr int kWave = 64;
 constexpr int kMaxLayers = 256;
 constexpr int kMaxSteps = 4096;
-constexpr int kMaxTiles = 4096;
 constexpr int kNoRadius = 0xFF;
 
-enum FieldError : int { kErrRadiusOverflow = 1, kErrWorkOverflow = 2 };
+enum FieldError : int { kErrRadiusOverflow = 1 };
 
 struct LutView {
     const float* density; int nDensity;
@@ -49,7 +48,6 @@ struct FieldState {
     float entryZ, pxSpMultX, pxSpMultY;   // :784, :849
     int errorFlags;
     int maxRadius;
-    unsigned int workCount;
     long long liveSteps;
     int bboxMin[3], bboxMax[3];     // :1207-1208
     TransferParams transfer;        // :1213
@@ -68,26 +66,28 @@ struct FieldConst {
     float maxPeakDepth;             // kernel_wrapper.cu:792-794
     float bpDepthCutoff, convSigmaCutoff, ksSigmaCutoff, rayWeightCutoff;
     int doseToWater, nozzle;
-    unsigned int workCapacity;
 };
 
 // ------------------------------------------------------------------------------------------------
-// wave64 helpers
-__device__ inline float waveMin(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { float t = __shfl_xor(v, o, kWave); v = t < v ? t : v; }
-    return v;
+// wave64 helpers: butterfly reductions on DPP (quad_perm, row_half_mirror, row_mirror, row_bcast15/31) — VALU only, no
+// LDS crossbar (ds_bpermute) round trips; the total lands in lane 63 and is broadcast with v_readlane.
+template <typename T, typename Op>
+__device__ inline T waveReduce(T v, Op op) {
+    int x = __builtin_bit_cast(int, v);
+#define RTD_DPP_STEP(ctrl, rmask) { int t = __builtin_amdgcn_update_dpp(x, x, ctrl, rmask, 0xF, false); \
+                                    x = __builtin_bit_cast(int, op(__builtin_bit_cast(T, x), __builtin_bit_cast(T, t))); }
+    RTD_DPP_STEP(0xB1, 0xF)    // quad_perm [1,0,3,2]
+    RTD_DPP_STEP(0x4E, 0xF)    // quad_perm [2,3,0,1]
+    RTD_DPP_STEP(0x141, 0xF)   // row_half_mirror
+    RTD_DPP_STEP(0x140, 0xF)   // row_mirror     -> every lane of a 16-lane row holds the row's result
+    RTD_DPP_STEP(0x142, 0xA)   // row_bcast:15 into rows 1 and 3
+    RTD_DPP_STEP(0x143, 0xC)   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's result
+#undef RTD_DPP_STEP
+    return __builtin_bit_cast(T, __builtin_amdgcn_readlane(x, 63));
 }
-__device__ inline int waveMinI(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o, kWave); v = t < v ? t : v; }
-    return v;
-}
-__device__ inline int waveMaxI(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o, kWave); v = t > v ? t : v; }
-    return v;
-}
+__device__ inline float waveMin(float v) { return waveReduce(v, [](float a, float b) { return b < a ? b : a; }); }
+__device__ inline int waveMinI(int v) { return waveReduce(v, [](int a, int b) { return b < a ? b : a; }); }
+__device__ inline int waveMaxI(int v) { return waveReduce(v, [](int a, int b) { return b > a ? b : a; }); }
 __device__ inline int f2iSat(float v) { return (int)v; }   // v_cvt_i32_f32: NaN -> 0, saturating (same as the reference GPU)
 
 // ------------------------------------------------------------------------------------------------
@@ -138,15 +138,14 @@ __device__ inline float sample3dBorder(const float* __restrict__ vol, int nx, in
 
 // ------------------------------------------------------------------------------------------------
 // K0: reset the per-field device state (the reference re-creates these per beam, kernel_wrapper.cu:685-734).
-__global__ void k_reset(FieldState* st, LayerPlan* layers, int L, int* weplMinBits, int S) {
+__global__ void k_reset(FieldState* st, LayerPlan* layers, int L) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t == 0) {
         st->beamFirstInside = 0x7fffffff; st->beamFirstOutside = -0x7fffffff; st->firstGuaranteedPassive = 0;
-        st->firstCalculatedPassive = 0; st->errorFlags = 0; st->maxRadius = 0; st->workCount = 0; st->liveSteps = 0;
+        st->firstCalculatedPassive = 0; st->errorFlags = 0; st->maxRadius = 0; st->liveSteps = 0;
         st->empty = 0;
         for (int i = 0; i < 3; ++i) { st->bboxMin[i] = 0; st->bboxMax[i] = 0; }
     }
-    for (int k = t; k < S; k += gridDim.x * blockDim.x) weplMinBits[k] = 0x7f800000;  // +inf
     for (int l = t; l < L; l += gridDim.x * blockDim.x) {
         layers[l].layerFirstPassive = 0; layers[l].afterLast = 0;
         for (int i = 0; i < kMaxSuperpR + 2; ++i) { layers[l].hist[i] = 0; layers[l].effRad[i] = i; }
@@ -154,52 +153,103 @@ __global__ void k_reset(FieldState* st, LayerPlan* layers, int L, int* weplMinBi
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1: ray tracer = fillBevDensityAndSp (kernel_wrapper.cu:130-187) fused with the three reductions that follow
-// it in the reference (sliceMinVar/sliceMaxVar, kernel_wrapper.cu:781-790): per-step min WEPL, min firstInside,
-// max firstOutside. One thread per ray, block = one 32x8 tile of rays = 4 waves; the two HU LUTs live in LDS.
-// Stores are step-major and coalesced (32 consecutive floats per row).
-__global__ __launch_bounds__(256) void k_trace(const float* __restrict__ ct, int nx, int ny, int nz, LutView lut,
-                                                TracerParams tp, int W, int H, float* __restrict__ bevDensity,
-                                                float* __restrict__ bevCumulSp, int* __restrict__ firstInside,
-                                                int* __restrict__ firstOutside, int* __restrict__ weplMinBits,
-                                                FieldState* st) {
+// K1: ray tracer = fillBevDensityAndSp (kernel_wrapper.cu:130-187), split in two passes so that the 8 scattered CT
+// loads per sample (no texture unit on gfx950) run with (rays x segments) parallelism instead of one serial
+// 512-step walk per ray:
+//   k_trace_sample  one thread per (ray, segment of kTraceSeg steps): trilinear HU sample, density LUT, and the
+//                   step's stopping-power term stepLen*SP(hu). The sample position is advanced with the
+//                   reference's repeated `pos += step` (arithmetic only) so it is the same float sequence.
+//   k_trace_scan    one thread per ray: the reference's sequential sums (cumulSp, cumulHuPlus1000) and entry/exit
+//                   logic over the stored terms, fused with the int reductions that follow the tracer in the
+//                   reference (sliceMin/MaxVar<int>, kernel_wrapper.cu:781-787).
+// Rays are numbered row-major; lanes hold consecutive rays, so all stores are coalesced and step-major.
+constexpr int kTraceSeg = 32;
+
+__global__ __launch_bounds__(256) void k_trace_sample(const float* __restrict__ ct, int nx, int ny, int nz, LutView lut,
+                                                       TracerParams tp, int W, int H, float* __restrict__ bevDensity,
+                                                       float* __restrict__ spTerm, float* __restrict__ huBuf) {
     extern __shared__ float sLut[];
     float* sDensity = sLut;
     float* sSp = sLut + lut.nDensity;
-    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    const int tid = threadIdx.x;
     for (int i = tid; i < lut.nDensity; i += 256) sDensity[i] = lut.density[i];
     for (int i = tid; i < lut.nSp; i += 256) sSp[i] = lut.sp[i];
     __syncthreads();
 
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    const int ray = blockIdx.x * 256 + tid;
+    const int x = ray % W, y = ray / W;
     const size_t memStep = (size_t)W * H;
-    size_t idx = (size_t)y * W + x;
+    const unsigned int k0 = blockIdx.y * kTraceSeg;
+    const unsigned int k1 = min(k0 + kTraceSeg, tp.steps);
 
     Vec3 pos = tp.getStart(x, y);     // texel-centre +0.5 of kernel_wrapper.cu:142 is implicit in the sampler
     const Vec3 step = tp.getInc(x, y);
     const float stepLen = tp.stepLen(x, y);
-    float cumulSp = 0.0f, cumulHuPlus1000 = 0.0f;
-    int beforeFirstInside = -1, lastInside = -1;
-
-    for (unsigned int i = 0; i < tp.steps; ++i) {
-        float huPlus1000 = sample3dBorder(ct, nx, ny, nz, pos.x, pos.y, pos.z);
-        cumulHuPlus1000 += huPlus1000;
+    for (unsigned int i = 0; i < k0; ++i) pos = pos + step;          // same float sequence as the serial walk (:183)
+    size_t idx = (size_t)k0 * memStep + ray;
+    for (unsigned int i = k0; i < k1; ++i) {
+        const float huPlus1000 = sample3dBorder(ct, nx, ny, nz, pos.x, pos.y, pos.z);
+        huBuf[idx] = huPlus1000;
         bevDensity[idx] = sample1dClamp(sDensity, lut.nDensity, huPlus1000 * tp.densityScale);
-        cumulSp += stepLen * sample1dClamp(sSp, lut.nSp, huPlus1000 * tp.spScale);
-        if (cumulHuPlus1000 < 150.0f) beforeFirstInside = (int)i;
-        if (huPlus1000 > 150.0f) lastInside = (int)i;
-        bevCumulSp[idx] = cumulSp;
-        // fused sliceMinVar<float> over this step (WEPL >= 0, so the int order of the bit pattern is the float order)
-        float m = waveMin(cumulSp);
-        if ((tid & (kWave - 1)) == 0) atomicMin(&weplMinBits[i], __float_as_int(m));
+        spTerm[idx] = stepLen * sample1dClamp(sSp, lut.nSp, huPlus1000 * tp.spScale);
         idx += memStep;
         pos = pos + step;
     }
-    firstInside[(size_t)y * W + x] = beforeFirstInside + 1;
-    firstOutside[(size_t)y * W + x] = lastInside + 1;
+}
+
+__global__ __launch_bounds__(64) void k_trace_scan(const float* __restrict__ huBuf, float* __restrict__ bevCumulSp, int W, int H,
+                                                    unsigned int steps, int* __restrict__ firstInside, int* __restrict__ firstOutside,
+                                                    FieldState* st) {
+    const int ray = blockIdx.x * 64 + threadIdx.x;
+    const size_t memStep = (size_t)W * H;
+    size_t idx = ray;
+    float cumulSp = 0.0f, cumulHuPlus1000 = 0.0f;
+    int beforeFirstInside = -1, lastInside = -1;
+    // batches of kScanBatch steps: all loads of a batch are issued before the serial sums consume them, so the
+    // walk is bound by arithmetic, not by one memory round trip per step
+    constexpr int kScanBatch = 16;
+    for (unsigned int i0 = 0; i0 < steps; i0 += kScanBatch) {
+        float hu[kScanBatch], sp[kScanBatch];
+#pragma unroll
+        for (int j = 0; j < kScanBatch; ++j) {
+            const bool in = i0 + j < steps;
+            hu[j] = in ? huBuf[idx + (size_t)j * memStep] : 0.0f;
+            sp[j] = in ? bevCumulSp[idx + (size_t)j * memStep] : 0.0f;   // holds stepLen*SP(hu) from k_trace_sample
+        }
+#pragma unroll
+        for (int j = 0; j < kScanBatch; ++j) {
+            const unsigned int i = i0 + j;
+            if (i < steps) {
+                const float huPlus1000 = hu[j];
+                cumulHuPlus1000 += huPlus1000;
+                cumulSp += sp[j];
+                if (cumulHuPlus1000 < 150.0f) beforeFirstInside = (int)i;
+                if (huPlus1000 > 150.0f) lastInside = (int)i;
+                bevCumulSp[idx + (size_t)j * memStep] = cumulSp;
+            }
+        }
+        idx += (size_t)kScanBatch * memStep;
+    }
+    firstInside[ray] = beforeFirstInside + 1;
+    firstOutside[ray] = lastInside + 1;
     int mn = waveMinI(beforeFirstInside + 1), mx = waveMaxI(lastInside + 1);
-    if ((tid & (kWave - 1)) == 0) { atomicMin(&st->beamFirstInside, mn); atomicMax(&st->beamFirstOutside, mx); }
+    if (threadIdx.x == 0) { atomicMin(&st->beamFirstInside, mn); atomicMax(&st->beamFirstOutside, mx); }
+}
+
+// sliceMinVar<float> (kernel_wrapper.cuh:215-244, launch kernel_wrapper.cu:788): smallest WEPL of every step.
+// One block per step; unlike the reference there is no n >= blockSize assumption.
+__global__ __launch_bounds__(256) void k_slice_min(const float* __restrict__ bevCumulSp, size_t n, int* __restrict__ weplMinBits) {
+    __shared__ float sM[4];
+    const float* p = bevCumulSp + (size_t)blockIdx.x * n;
+    float m = __int_as_float(0x7f800000);
+    for (size_t i = threadIdx.x; i < n; i += 256) { float t = p[i]; m = t < m ? t : m; }
+    m = waveMin(m);
+    if ((threadIdx.x & (kWave - 1)) == 0) sM[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = sM[0]; m = sM[1] < m ? sM[1] : m; m = sM[2] < m ? sM[2] : m; m = sM[3] < m ? sM[3] : m;
+        weplMinBits[blockIdx.x] = __float_as_int(m);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -292,22 +342,21 @@ __global__ void k_conv_y(const float* __restrict__ in, float* __restrict__ out, 
 // ------------------------------------------------------------------------------------------------
 // K5: IDD + sigma fill = fillIddAndSigma without NUCLEAR_CORR (kernel_wrapper.cu:190-379), all energy layers in
 // one launch (blockIdx.z = layer), fused with the reductions and the classification that follow it in the
-// reference: layerFirstPassive (sliceMaxVar, :952-957), the per-tile radius class + histogram (tileRadCalc,
-// kernel_wrapper.cuh:256-313) and the list of tiles that hold dose (replaces the per-radius tile lists).
-// Block = one 32x8 classification tile = 4 waves; the serial recurrence along the ray is kept in the
-// reference's order ("a bit of a mine field", kernel_wrapper.cuh:144).
+// reference: layerFirstPassive (sliceMaxVar, :952-957) and the per-tile radius class + histogram (tileRadCalc,
+// kernel_wrapper.cuh:256-313). Block = one 32x8 classification tile = 4 waves. The layer's two cumulative-IDD
+// rows and the 1/X0 table are staged in LDS (the reference fetches them through textures, :269-274,:285-290);
+// WEPL and density of the next step are prefetched while the current step's serial recurrence runs. The
+// recurrence itself keeps the reference's order ("a bit of a mine field", kernel_wrapper.cuh:144).
+template <bool LDS_LUT>
 __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensity, const float* __restrict__ bevCumulSp,
                                                float* __restrict__ bevIdd, float* __restrict__ bevRSigmaEff,
                                                const float* __restrict__ rayWeights, const int* __restrict__ firstInside,
                                                const int* __restrict__ firstOutside, int* __restrict__ firstPassive,
-                                               unsigned char* __restrict__ tileRad, unsigned int* __restrict__ workList,
-                                               LayerPlan* layers, FieldState* st, LutView lut, FillGeom fg, FieldConst fc) {
-    __shared__ float sMin[2][4];
-    __shared__ int sAny[2][4];
+                                               unsigned char* __restrict__ tileRad, LayerPlan* layers, FieldState* st,
+                                               LutView lut, FillGeom fg, FieldConst fc) {
+    extern __shared__ float sLutF[];
+    __shared__ float sMin[8][4];
     __shared__ int sHist[kMaxSuperpR + 2];
-    __shared__ unsigned int sItems[kMaxSteps];
-    __shared__ int sItemCount;
-    __shared__ unsigned int sBase;
 
     const int layer = blockIdx.z;
     const int tid = threadIdx.y * blockDim.x + threadIdx.x;
@@ -320,10 +369,27 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
     const size_t rayIdx = (size_t)y * W + x;
     size_t idx = rayIdx;
 
-    if (tid < kMaxSuperpR + 2) sHist[tid] = 0;
-    if (tid == 0) sItemCount = 0;
-
     const LayerPlan lp = layers[layer];
+    // cumulative IDD: rows floor(energyIdx), floor(energyIdx)+1 (CLAMP) and the row weight are layer constants
+    int ey0, ey1; float eay;
+    {
+        float py = lp.energyIdx, fy = floorf(py);
+        eay = py - fy; ey0 = (int)fy; ey1 = ey0 + 1;
+        if (!(py >= 0.0f)) { ey0 = 0; ey1 = 0; eay = 0.0f; }
+        ey0 = ey0 > lut.nEnergies - 1 ? lut.nEnergies - 1 : ey0;
+        ey1 = ey1 > lut.nEnergies - 1 ? lut.nEnergies - 1 : ey1;
+    }
+    const float* gRow0 = lut.cidd + (size_t)ey0 * lut.nSamples;
+    const float* gRow1 = lut.cidd + (size_t)ey1 * lut.nSamples;
+    float* sRow0 = sLutF;
+    float* sRow1 = sLutF + lut.nSamples;
+    float* sRrl = sLutF + 2 * lut.nSamples;
+    if (LDS_LUT) {
+        for (int i = tid; i < lut.nSamples; i += 256) { sRow0[i] = gRow0[i]; sRow1[i] = gRow1[i]; }
+        for (int i = tid; i < lut.nRrl; i += 256) sRrl[i] = lut.rrl[i];
+    }
+    if (tid < kMaxSuperpR + 2) sHist[tid] = 0;
+
     const unsigned int pFirst = (unsigned int)st->beamFirstInside;
     const unsigned int pAfterLast = st->empty ? pFirst : (unsigned int)lp.afterLast;
 
@@ -345,15 +411,39 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
     __syncthreads();
 
     idx += (size_t)pFirst * memStep;
-    for (unsigned int stepNo = pFirst; stepNo < pAfterLast; ++stepNo) {
+    constexpr int kFillBatch = 8;   // WEPL/density of a batch of steps are loaded up front (independent of the recurrence)
+    for (unsigned int step0 = pFirst; step0 < pAfterLast; step0 += kFillBatch) {
+      float spB[kFillBatch], denB[kFillBatch], rsB[kFillBatch];
+#pragma unroll
+      for (int j = 0; j < kFillBatch; ++j) {
+          const bool in = step0 + j < pAfterLast;
+          spB[j] = in ? bevCumulSp[idx + (size_t)j * memStep] : 0.0f;
+          denB[j] = in ? bevDensity[idx + (size_t)j * memStep] : 0.0f;
+      }
+#pragma unroll
+      for (int j = 0; j < kFillBatch; ++j) {
+        const unsigned int stepNo = step0 + j;
+        rsB[j] = __int_as_float(0x7f800000);
+        if (stepNo >= pAfterLast) continue;                          // block-uniform
+        const float curSp = spB[j], curDensity = denB[j];
         if (beamLive) {
-            cumulSp = bevCumulSp[idx];
-            cumulDose = sample2dClamp(lut.cidd, lut.nSamples, lut.nEnergies, cumulSp * lp.energyScaleFact, lp.energyIdx);
-            float density = bevDensity[idx];
+            cumulSp = curSp;
+            {   // tex2D(cumulIddTex, ...) :269-274, rows and row weight hoisted
+                float px = cumulSp * lp.energyScaleFact;
+                float fx = floorf(px), ax = px - fx;
+                int x0 = (int)fx, x1 = x0 + 1;
+                if (!(px >= 0.0f)) { x0 = 0; x1 = 0; ax = 0.0f; }
+                x0 = x0 > lut.nSamples - 1 ? lut.nSamples - 1 : x0; x1 = x1 > lut.nSamples - 1 ? lut.nSamples - 1 : x1;
+                float r0 = LDS_LUT ? lerpW(ax, sRow0[x0], sRow0[x1]) : lerpW(ax, gRow0[x0], gRow0[x1]);
+                float r1 = LDS_LUT ? lerpW(ax, sRow1[x0], sRow1[x1]) : lerpW(ax, gRow1[x0], gRow1[x1]);
+                cumulDose = lerpW(eay, r0, r1);
+            }
+            float density = curDensity;
             if (cumulSp < lp.peakDepth) {
                 float resE = eCoef * powf(lp.peakDepth - 0.5f * (cumulSp + cumulSpOld), pInv);
                 float betaP = resE + 938.3f - 938.3f * 938.3f / (resE + 938.3f);
-                float rRl = density * sample1dClamp(lut.rrl, lut.nRrl, density * fg.rRlScale);
+                float rRl = density * (LDS_LUT ? sample1dClamp(sRrl, lut.nRrl, density * fg.rRlScale)
+                                               : sample1dClamp(lut.rrl, lut.nRrl, density * fg.rRlScale));
                 float thetaSq = eRefSq / (betaP * betaP) * fg.stepLength * rRl;
                 sigmaSq += incScat + incDiv;
                 incincScat += 2.0f * thetaSq * fg.stepLength * fg.stepLength;
@@ -374,37 +464,33 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
         bevIdd[layerOff + idx] = res;
         bevRSigmaEff[layerOff + idx] = rSigmaEff;
 
-        // fused tileRadCalc: min of 1/sigma over the 32x8 tile -> radius class; any(dose>0) -> work item
-        const int buf = stepNo & 1;
-        float wm = waveMin(rSigmaEff);
-        int wa = __any(res > 0.0f);
-        if ((tid & (kWave - 1)) == 0) { sMin[buf][wave] = wm; sAny[buf][wave] = wa; }
-        __syncthreads();
-        if (tid == 0) {
-            float m = sMin[buf][0];
-            m = sMin[buf][1] < m ? sMin[buf][1] : m; m = sMin[buf][2] < m ? sMin[buf][2] : m; m = sMin[buf][3] < m ? sMin[buf][3] : m;
-            int rad = f2iSat(fc.ksSigmaCutoff / (sqrtf(2.0f) * m) + 0.5f);
-            rad = rad > kMaxSuperpR + 1 ? kMaxSuperpR + 1 : rad;
-            rad = rad < 0 ? 0 : rad;
-            tileRad[((size_t)layer * fc.S + stepNo) * nTiles + tileNo] = (unsigned char)rad;
-            sHist[rad] += 1;
-            if (sAny[buf][0] | sAny[buf][1] | sAny[buf][2] | sAny[buf][3])
-                sItems[sItemCount++] = ((unsigned int)layer << 24) | (stepNo << 12) | (unsigned int)tileNo;
-        }
+        rsB[j] = rSigmaEff;
         idx += memStep;
+      }
+      // fused tileRadCalc: min of 1/sigma over the 32x8 tile -> radius class of every (layer, step, tile) of the batch;
+      // one LDS exchange and one barrier per batch of steps
+#pragma unroll
+      for (int j = 0; j < kFillBatch; ++j) {
+          float wm = waveMin(rsB[j]);
+          if ((tid & (kWave - 1)) == 0) sMin[j][wave] = wm;
+      }
+      __syncthreads();
+      if (tid < kFillBatch && step0 + tid < pAfterLast) {
+          float m = sMin[tid][0];
+          m = sMin[tid][1] < m ? sMin[tid][1] : m; m = sMin[tid][2] < m ? sMin[tid][2] : m; m = sMin[tid][3] < m ? sMin[tid][3] : m;
+          int rad = f2iSat(fc.ksSigmaCutoff / (sqrtf(2.0f) * m) + 0.5f);
+          rad = rad > kMaxSuperpR + 1 ? kMaxSuperpR + 1 : rad;
+          rad = rad < 0 ? 0 : rad;
+          tileRad[((size_t)layer * fc.S + step0 + tid) * nTiles + tileNo] = (unsigned char)rad;
+          atomicAdd(&sHist[rad], 1);
+      }
+      __syncthreads();
     }
     firstPassive[(size_t)layer * memStep + rayIdx] = (int)afterLast;
     int mx = waveMaxI((int)afterLast);
     if ((tid & (kWave - 1)) == 0) atomicMax(&layers[layer].layerFirstPassive, mx);
     __syncthreads();
     if (tid < kMaxSuperpR + 2 && sHist[tid] > 0) atomicAdd(&layers[layer].hist[tid], sHist[tid]);
-    if (tid == 0) {
-        unsigned int base = sItemCount ? atomicAdd(&st->workCount, (unsigned int)sItemCount) : 0u;
-        if (base + (unsigned int)sItemCount > fc.workCapacity) { atomicOr(&st->errorFlags, kErrWorkOverflow); sItemCount = 0; }
-        sBase = base;
-    }
-    __syncthreads();
-    for (int i = tid; i < sItemCount; i += 256) workList[sBase + i] = sItems[i];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -468,78 +554,7 @@ __global__ void k_ks_plan(FieldState* st, LayerPlan* layers, FieldConst fc, From
 }
 
 // ------------------------------------------------------------------------------------------------
-// K7 (v1): kernel superposition = kernelSuperposition<rad> (kernel_wrapper.cuh:432-489). One work item = one
-// 32x8 source tile at one (layer, step) that holds dose. Persistent blocks stride over the device-side work
-// list; the extent radius is the batch radius effRad[tileRad] exactly as the reference's batched launches.
-// Per source voxel: erf-difference weights e[0..rad] (LDS table, one row per thread), then (2rad+1)^2 LDS
-// LDS read-modify-writes into the block's (32+2rad)x(8+2rad) tile, then a flush with global float atomics.
-__global__ __launch_bounds__(256) void k_superpose(const float* __restrict__ bevIdd, const float* __restrict__ bevRSigmaEff,
-                                                    float* __restrict__ bevDose, const unsigned char* __restrict__ tileRad,
-                                                    const unsigned int* __restrict__ workList, const LayerPlan* __restrict__ layers,
-                                                    const FieldState* __restrict__ st, FieldConst fc) {
-    constexpr int TW = kSuperpTileX + 2 * kMaxSuperpR;   // 96
-    constexpr int TH = kSuperpTileY + 2 * kMaxSuperpR;   // 72
-    constexpr int ES = kMaxSuperpR + 1;                  // table stride 33 dwords: odd -> lanes hit distinct LDS banks
-    __shared__ float tile[TW * TH];
-    __shared__ float eTab[256 * ES];
-    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
-    const unsigned int count = st->workCount < fc.workCapacity ? st->workCount : fc.workCapacity;
-    const size_t memStep = (size_t)fc.W * fc.H;
-    const int nTiles = fc.tilesX * fc.tilesY;
-    const int outPitch = fc.bevW;
-    const size_t outSlice = (size_t)fc.bevW * fc.bevH;
-
-    for (unsigned int w = blockIdx.x; w < count; w += gridDim.x) {
-        const unsigned int item = workList[w];
-        const int layer = item >> 24, k = (item >> 12) & 0xFFF, tileNo = item & 0xFFF;
-        const int ownRad = tileRad[((size_t)layer * fc.S + k) * nTiles + tileNo];
-        if (ownRad > kMaxSuperpR) continue;                  // overflow is reported through errorFlags
-        const int rad = layers[layer].effRad[ownRad];
-        const int tw = kSuperpTileX + 2 * rad, th = kSuperpTileY + 2 * rad;
-        const int bx = tileNo % fc.tilesX, by = tileNo / fc.tilesX;
-        for (int i = tid; i < tw * th; i += 256) tile[i] = 0.0f;
-
-        const size_t inIdx = (size_t)layer * memStep * fc.S + (size_t)k * memStep
-                             + (size_t)(by * kSuperpTileY + threadIdx.y) * fc.W + bx * kSuperpTileX + threadIdx.x;
-        const float dose = bevIdd[inIdx];
-        const float rSigmaEff = bevRSigmaEff[inIdx];
-        float* e = eTab + tid * ES;
-        {   // erfDiffs (kernel_wrapper.cuh:459-467)
-            float erfNew = erff(rSigmaEff * 0.5f);
-            float erfOld = -erfNew;
-            for (int i = 0; i <= rad; ++i) {
-                e[i] = 0.5f * (erfNew - erfOld);
-                erfOld = erfNew;
-                erfNew = erff(rSigmaEff * ((float)i + 1.5f));
-            }
-        }
-        __syncthreads();
-        const int row = threadIdx.y, col = threadIdx.x;
-        // Conflict-free schedule of the reference (kernel_wrapper.cuh:468-476), valid for wave64: at a given i every
-        // thread (row, col) updates tile[row+i][col+j] — distinct elements for all 256 threads — and the lanes of one
-        // wave (two full rows) walk j in lockstep; a barrier separates successive i.
-        for (int i = 0; i < 2 * rad + 1; ++i) {
-            const float wi = dose * e[abs(rad - i)];
-            // volatile: lane c's update of column c+j must stay ordered after lane c+1's update of the same column at
-            // tap j-1 (same wave, lockstep) — the compiler may not batch loads of several taps ahead of the stores
-            volatile float* trow = tile + (row + i) * tw + col;
-            for (int j = 0; j < 2 * rad + 1; ++j) trow[j] = trow[j] + wi * e[abs(rad - j)];
-            __syncthreads();
-        }
-        // flush (kernel_wrapper.cuh:480-488): tile element (r, c) -> bev[k][by*8 + r + 32 - rad][bx*32 + c + 32 - rad]
-        float* out = bevDose + (size_t)k * outSlice + (size_t)(by * kSuperpTileY + kMaxSuperpR - rad) * outPitch
-                     + bx * kSuperpTileX + kMaxSuperpR - rad;
-        for (int i = tid; i < tw * th; i += 256) {
-            int r = i / tw, c = i - r * tw;
-            float v = tile[i];
-            if (v != 0.0f) unsafeAtomicAdd(out + (size_t)r * outPitch + c, v);
-        }
-        __syncthreads();
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K7 (v2): output-stationary kernel superposition on the matrix cores, one autonomous WAVE per work item.
+// K7: output-stationary kernel superposition on the matrix cores, one autonomous WAVE per work item.
 //
 // Same arithmetic as kernelSuperposition<rad> (kernel_wrapper.cuh:432-489): every source voxel s adds the
 // separable patch  dose_s * e_s[|dy|] * e_s[|dx|],  |dy|,|dx| <= rho_s  (rho_s = batch radius of its 32x8 tile,
@@ -726,21 +741,22 @@ __global__ __launch_bounds__(256) void k_superpose_reduce(const float* __restric
 // K8: fan -> dose-grid transfer = primTransfDiv (kernel_wrapper.cu:69-97). The reference copies the BEV slab
 // into a 3-D texture first (:1107-1141); here the trilinear BORDER sample is taken from the BEV buffer itself
 // (slab origin and extent applied in index arithmetic), which removes that copy. One thread per dose (x,y)
-// column inside the device-side bounding box, walking z.
+// column and z-chunk inside the device-side bounding box (getFanIdx(z) is closed-form, so z splits freely).
 __global__ __launch_bounds__(256) void k_transfer(float* __restrict__ dose, int nx, int ny, int nz,
                                                    const float* __restrict__ bevDose, const FieldState* __restrict__ st,
-                                                   FieldConst fc) {
+                                                   FieldConst fc, int zChunk) {
     const int first = st->beamFirstInside;
     const int slabZ = st->firstCalculatedPassive - first;
     if (slabZ <= 0) return;
     const int x = st->bboxMin[0] + blockDim.x * blockIdx.x + threadIdx.x;
     const int y = st->bboxMin[1] + blockDim.y * blockIdx.y + threadIdx.y;
     const int xEnd = st->bboxMin[0] + ((st->bboxMax[0] - st->bboxMin[0] + 1 + 31) / 32) * 32;
-    if (x >= xEnd || y > st->bboxMax[1] || x >= nx || y >= ny) return;
+    const int z0 = st->bboxMin[2] + blockIdx.z * zChunk;
+    const int z1 = min(z0 + zChunk - 1, st->bboxMax[2]);
+    if (x >= xEnd || y > st->bboxMax[1] || x >= nx || y >= ny || z0 > z1) return;
     TransferParams p = st->transfer;
     p.init(x, y);
     const float* slab = bevDose + (size_t)first * fc.bevW * fc.bevH;
-    const int z0 = st->bboxMin[2], z1 = st->bboxMax[2];
     float* res = dose + (size_t)z0 * nx * ny + (size_t)y * nx + x;
     for (int z = z0; z <= z1; ++z) {
         Vec3 pos = p.getFanIdx(z);

@@ -1,0 +1,31 @@
+"""Multi-GPU plan execution: fields shard one-per-rank, per-rank dose volumes are summed into rank 0.
+
+The reference has no multi-GPU code (its beam loop, src/kernel_wrapper.cu:601, accumulates every beam into one
+device dose volume, :92). Beams are independent until that accumulation, so a plan shards by field with no
+data-path exchange except ONE float32 sum-reduce of the dose volume (RCCL over xGMI when the tensors live on
+GPUs; gloo in the CPU tests). Sum order differs from the sequential reference by float rounding only.
+"""
+
+
+def shard_fields(n_fields, world_size, rank):
+    """Indices of the fields rank `rank` computes: round-robin, so 4 fields on 4 ranks = one each."""
+    if world_size <= 0 or not (0 <= rank < world_size):
+        raise ValueError("bad rank/world_size")
+    return list(range(rank, n_fields, world_size))
+
+
+def reduce_dose(dose_tensor, dist=None, dst=0):
+    """Sum the per-rank dose volumes into rank `dst` (in place on dst). No-op without a process group."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return dose_tensor
+    dist.reduce(dose_tensor, dst=dst, op=dist.ReduceOp.SUM)
+    return dose_tensor
+
+
+def run_plan(compute_field, n_fields, dose_tensor, dist=None, dst=0):
+    """Compute this rank's shard (compute_field(i) accumulates field i into dose_tensor) and reduce to dst."""
+    world = dist.get_world_size() if (dist is not None and dist.is_initialized()) else 1
+    rank = dist.get_rank() if world > 1 else 0
+    for i in shard_fields(n_fields, world, rank):
+        compute_field(i)
+    return reduce_dose(dose_tensor, dist, dst)

@@ -1,0 +1,63 @@
+"""N>1 path on CPU: two gloo ranks each compute their shard of a 2-field plan (the oracle stands in for the per-rank
+engine), one sum-reduce to rank 0, result == sequential accumulation of both fields (the reference's beam loop)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from raytracedicom_amd import plan
+
+
+def test_shard_fields():
+    assert plan.shard_fields(4, 4, 2) == [2]
+    assert plan.shard_fields(8, 4, 1) == [1, 5]
+    assert plan.shard_fields(1, 2, 1) == []
+    assert sorted(sum((plan.shard_fields(7, 3, r) for r in range(3)), [])) == list(range(7))
+    with pytest.raises(ValueError):
+        plan.shard_fields(4, 2, 2)
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle
+    from raytracedicom_amd import luts, scenarios
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    oracle.set_threads(2)
+    es = luts.synth_luts()
+    ct, _ = scenarios.hetero_phantom(64)
+    scn = scenarios.hetero_ct(es, n=64, spots=4, pitch=8.0, n_layers=2, angles=[0.0, 90.0], ct=ct)
+    dose = np.zeros_like(scn.ct)
+    t = torch.from_numpy(dose)
+
+    def compute_field(i):
+        f = oracle.run_field(scn, scn.beams[i], dose, keep_layers=False)
+        assert f.status == 0
+        f.close()
+
+    plan.run_plan(compute_field, len(scn.beams), t, dist, dst=0)
+    if rank == 0:
+        np.save(out_path, dose)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_plan_equals_sequential(orc, synth, tmp_path):
+    import torch.multiprocessing as mp
+    from raytracedicom_amd import scenarios
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "dose.npy")
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    ct, _ = scenarios.hetero_phantom(64)
+    scn = scenarios.hetero_ct(synth, n=64, spots=4, pitch=8.0, n_layers=2, angles=[0.0, 90.0], ct=ct)
+    ref = orc.compute(scn)
+    assert ref.max() > 0
+    np.testing.assert_allclose(got, ref, rtol=1e-6, atol=1e-12 * float(ref.max()))
