@@ -470,7 +470,7 @@ int rtd_field_compute(rtd_handle hh, rtd_field ff, float* dev_dose) {
         const int nTX = (fc.bevW + kKsTileX - 1) / kKsTileX, nTY = (fc.bevH + kKsTileY - 1) / kKsTileY;
         const int G = f->ksGroups;
         const int nItems = fc.S * G * nTY * nTX;
-        k_superpose_mfma<<<(nItems + 3) / 4, 256, 0, s>>>(f->dIdd, f->dRSigma, f->dBevPart, f->dTileRad, f->dLayers, f->dState, fc, nTX, nTY, G);
+        k_superpose_mfma<<<nItems, 64, 0, s>>>(f->dIdd, f->dRSigma, f->dBevPart, f->dTileRad, f->dLayers, f->dState, fc, nTX, nTY, G);
         k_superpose_reduce<<<1024, 256, 0, s>>>(f->dBevPart, f->dBev, f->dState, fc, G);
     }
     if (timing) RTD_HIP(h, hipEventRecord(f->ev[5], s));

@@ -576,15 +576,15 @@ constexpr int kKsMaxGroups = 32;              // upper bound of layer groups (= 
 
 __device__ inline int clampI(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-__global__ __launch_bounds__(256, 4) void k_superpose_mfma(const float* __restrict__ bevIdd, const float* __restrict__ bevRSigmaEff,
+__global__ __launch_bounds__(64, 4) void k_superpose_mfma(const float* __restrict__ bevIdd, const float* __restrict__ bevRSigmaEff,
                                                             float* __restrict__ bevPart, const unsigned char* __restrict__ tileRad,
                                                             const LayerPlan* __restrict__ layers, const FieldState* __restrict__ st,
                                                             FieldConst fc, int nTX, int nTY, int G) {
-    __shared__ float ldsAll[4 * kKsWaveLds];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float* lds = ldsAll + wave * kKsWaveLds;
+    __shared__ float lds[kKsWaveLds];
+    const int lane = threadIdx.x;
+    // One wave per block: a heavy item never keeps three finished neighbours' LDS and wave slots occupied.
     // decode the work item (wave-uniform): fastest index = tile x, then tile y, then group, then step
-    int item = blockIdx.x * 4 + wave;
+    int item = blockIdx.x;
     const int tX = item % nTX; item /= nTX;
     const int tY = item % nTY; item /= nTY;
     const int g = item % G;
@@ -678,15 +678,17 @@ __global__ __launch_bounds__(256, 4) void k_superpose_mfma(const float* __restri
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             // ---- accumulate: one MFMA per (source quad, 16x16 output tile) pair whose bands intersect ----
-            const int nq = (min(CS, nSrc - s0) + 3) >> 2;
-            const int r0 = s0 / nCols;
-            int qRow = ry0 + r0, qCol = s0 - r0 * nCols;             // wave-uniform position of the current quad
-            const float* mq = lds + kq * T + Tm;                     // lane's source of quad 0
-            const int liA = oy0 + li - 32, liB = li - kq - 32 - cx0; // lane constants of the A / B table indices
-            for (int q = 0; q < nq; ++q, qCol += 4, mq += 4 * T) {
-                if (qCol >= nCols) { qCol = 0; ++qRow; }
+            // Only quads that carry dose are visited: their lanes are taken from a wave ballot (scalar bit scan), the
+            // quad's grid position from the lane that built its first source.
+            unsigned long long live = __ballot(dose != 0.0f);
+            const int liA = oy0 + li - 32, liB = li - kq - 32 - cx0;   // lane constants of the A / B table indices
+            while (live) {
+                const int q = (__builtin_ctzll(live)) >> 2;
+                live &= ~(0xFull << (4 * q));
+                const int qRow = __builtin_amdgcn_readlane(sy, 4 * q);
+                const int qCol = __builtin_amdgcn_readlane(sx, 4 * q) - cx0;
                 const float dl = dArr[4 * q + kq];
-                if (!__any(dl != 0.0f)) continue;                    // quad carries no dose
+                const float* mq = lds + (4 * q + kq) * T + Tm;
                 const int psy = qRow + 32, psx0 = cx0 + qCol + 32;   // padded coordinates of the quad's first source
                 const bool ya0 = (oy0 <= psy + rho) && (oy0 + 15 >= psy - rho);
                 const bool ya1 = (oy0 + 16 <= psy + rho) && (oy0 + 31 >= psy - rho);
