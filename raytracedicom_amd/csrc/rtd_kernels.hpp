@@ -571,12 +571,12 @@ __global__ void k_ks_plan(FieldState* st, LayerPlan* layers, FieldConst fc, From
 // once and k_superpose_reduce adds the G partials in fixed order, so the BEV dose is bitwise reproducible.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kKsTileX = 64, kKsTileY = 32;   // output tile owned by one wave (4 x 2 MFMA tiles)
-constexpr int kKsWaveLds = 2560;              // floats of LDS per wave (10 KiB): tables [CS][T] + doses [CS]
+constexpr int kKsWaveLds = 1600;              // floats of LDS per wave (10 KiB): tables [CS][T] + doses [CS]
 constexpr int kKsMaxGroups = 32;              // upper bound of layer groups (= partial BEV buffers)
 
 __device__ inline int clampI(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-__global__ __launch_bounds__(64, 4) void k_superpose_mfma(const float* __restrict__ bevIdd, const float* __restrict__ bevRSigmaEff,
+__global__ __launch_bounds__(64, 6) void k_superpose_mfma(const float* __restrict__ bevIdd, const float* __restrict__ bevRSigmaEff,
                                                             float* __restrict__ bevPart, const unsigned char* __restrict__ tileRad,
                                                             const LayerPlan* __restrict__ layers, const FieldState* __restrict__ st,
                                                             FieldConst fc, int nTX, int nTY, int G) {
@@ -687,21 +687,25 @@ __global__ __launch_bounds__(64, 4) void k_superpose_mfma(const float* __restric
                 live &= ~(0xFull << (4 * q));
                 const int qRow = __builtin_amdgcn_readlane(sy, 4 * q);
                 const int qCol = __builtin_amdgcn_readlane(sx, 4 * q) - cx0;
-                const float dl = dArr[4 * q + kq];
                 const float* mq = lds + (4 * q + kq) * T + Tm;
+                // all seven LDS operands are fetched up front (clamped indices hit the zero ends of the table when a tile
+                // is out of the source's reach), then the MFMAs issue back to back under wave-uniform predicates
+                const int iy = liA - qRow, ix = liB - qCol;
+                const float dl = dArr[4 * q + kq];
+                const float e0 = mq[min(max(iy, -Tm), Tm)], e1 = mq[min(max(iy + 16, -Tm), Tm)];
+                const float b0 = mq[min(max(ox0 + ix, -Tm), Tm)], b1 = mq[min(max(ox0 + 16 + ix, -Tm), Tm)];
+                const float b2 = mq[min(max(ox0 + 32 + ix, -Tm), Tm)], b3 = mq[min(max(ox0 + 48 + ix, -Tm), Tm)];
                 const int psy = qRow + 32, psx0 = cx0 + qCol + 32;   // padded coordinates of the quad's first source
                 const bool ya0 = (oy0 <= psy + rho) && (oy0 + 15 >= psy - rho);
                 const bool ya1 = (oy0 + 16 <= psy + rho) && (oy0 + 31 >= psy - rho);
-                float a0 = 0.0f, a1 = 0.0f;
-                if (ya0) a0 = dl * mq[clampI(liA - qRow, -Tm, Tm)];
-                if (ya1) a1 = dl * mq[clampI(liA + 16 - qRow, -Tm, Tm)];
+                const float a0 = dl * e0, a1 = dl * e1;
+                const float bb[4] = {b0, b1, b2, b3};
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int x0 = ox0 + 16 * t;
                     if ((x0 <= psx0 + 3 + rho) && (x0 + 15 >= psx0 - rho)) {
-                        const float b = mq[clampI(x0 + liB - qCol, -Tm, Tm)];
-                        if (ya0) acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[0][t], 0, 0, 0);
-                        if (ya1) acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[1][t], 0, 0, 0);
+                        if (ya0) acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bb[t], acc[0][t], 0, 0, 0);
+                        if (ya1) acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bb[t], acc[1][t], 0, 0, 0);
                     }
                 }
             }
