@@ -60,6 +60,7 @@ struct rtd_field_impl {
     int *dFirstInside = nullptr, *dFirstOutside = nullptr, *dFirstPassive = nullptr, *dWeplMin = nullptr;
     unsigned char* dTileRad = nullptr;
     LayerPlan* dLayers = nullptr;
+    float* dStepTab = nullptr;
     FieldState* dState = nullptr;
     std::vector<LayerPlan> hLayers;
     hipEvent_t ev[8] = {};
@@ -318,7 +319,7 @@ int rtd_field_destroy(rtd_handle hh, rtd_field ff) {
     (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = { f->dSpotWeights, f->dConvInterm, f->dRayWeights, f->dDensity, f->dWepl, f->dIdd, f->dRSigma, f->dBev, f->dBevPart,
                      f->dFirstInside, f->dFirstOutside, f->dFirstPassive, f->dWeplMin, f->dTileRad,
-                     f->dLayers, f->dState };
+                     f->dLayers, f->dState, f->dStepTab };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : f->ev) if (e) (void)hipEventDestroy(e);
     delete f;
@@ -412,11 +413,20 @@ int rtd_field_create(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dims[
     A(&f->dSpotWeights, nSpot); A(&f->dConvInterm, (size_t)W * b->spot_ny * L); A(&f->dRayWeights, R * L);
     A(&f->dDensity, R * S); A(&f->dWepl, R * S); A(&f->dIdd, R * S * L); A(&f->dRSigma, R * S * L); A(&f->dBev, P * S); A(&f->dBevPart, P * S * f->ksGroups);
     A(&f->dFirstInside, R); A(&f->dFirstOutside, R); A(&f->dFirstPassive, R * L); A(&f->dWeplMin, (size_t)S);
-    A(&f->dTileRad, (size_t)L * S * tilesX * tilesY); A(&f->dLayers, (size_t)L); A(&f->dState, (size_t)1);
+    A(&f->dTileRad, (size_t)L * S * tilesX * tilesY); A(&f->dLayers, (size_t)L); A(&f->dState, (size_t)1); A(&f->dStepTab, (size_t)2 * S);
     if (st != RTD_OK) { rtd_field_destroy(hh, reinterpret_cast<rtd_field>(f)); return st; }
     hipError_t e = hipMemcpy(f->dSpotWeights, b->spot_weights, nSpot * sizeof(float), hipMemcpyHostToDevice);   // :851
     if (e == hipSuccess) e = hipMemcpy(f->dLayers, f->hLayers.data(), (size_t)L * sizeof(LayerPlan), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(f->dState, 0, sizeof(FieldState));
+    {
+        std::vector<float> tab(2 * (size_t)S);
+        for (int k = 0; k < S; ++k) {
+            Vec2 vw = f->fillGeom.voxelWidth((unsigned)k);
+            tab[2 * k] = 0.5f * (vw.x + vw.y);
+            tab[2 * k + 1] = f->fillGeom.stepVol((unsigned)k);
+        }
+        if (e == hipSuccess) e = hipMemcpy(f->dStepTab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice);
+    }
     for (auto& ev : f->ev) if (e == hipSuccess) e = hipEventCreate(&ev);
     if (e != hipSuccess) { h->error = std::string("HIP error: ") + hipGetErrorString(e); rtd_field_destroy(hh, reinterpret_cast<rtd_field>(f)); return RTD_ERR_HIP; }
     e = hipMemset(f->dBev, 0, P * (size_t)S * sizeof(float));   // slices outside [entry, passive) are never written: keep them zero
@@ -457,10 +467,10 @@ int rtd_field_compute(rtd_handle hh, rtd_field ff, float* dev_dose) {
         const dim3 fillGrid(rayGrid.x, rayGrid.y, fc.L);
         if (fillLds <= 96 * 1024)
             k_fill<true><<<fillGrid, blk, fillLds, s>>>(f->dDensity, f->dWepl, f->dIdd, f->dRSigma, f->dRayWeights, f->dFirstInside, f->dFirstOutside,
-                                                        f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc);
+                                                        f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc, f->dStepTab);
         else
             k_fill<false><<<fillGrid, blk, 0, s>>>(f->dDensity, f->dWepl, f->dIdd, f->dRSigma, f->dRayWeights, f->dFirstInside, f->dFirstOutside,
-                                                   f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc);
+                                                   f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc, f->dStepTab);
     }
     if (timing) RTD_HIP(h, hipEventRecord(f->ev[3], s));
     k_ks_plan<<<1, 64, 0, s>>>(f->dState, f->dLayers, fc, f->rayIdxToDoseIdx, f->transfer0, (int)f->doseDims[0], (int)f->doseDims[1],

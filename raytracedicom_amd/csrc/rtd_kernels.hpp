@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
                                                const float* __restrict__ rayWeights, const int* __restrict__ firstInside,
                                                const int* __restrict__ firstOutside, int* __restrict__ firstPassive,
                                                unsigned char* __restrict__ tileRad, LayerPlan* layers, FieldState* st,
-                                               LutView lut, FillGeom fg, FieldConst fc) {
+                                               LutView lut, FillGeom fg, FieldConst fc, const float* __restrict__ stepTab) {
     extern __shared__ float sLutF[];
     __shared__ float sMin[8][4];
     __shared__ int sHist[kMaxSuperpR + 2];
@@ -440,7 +440,8 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
             }
             float density = curDensity;
             if (cumulSp < lp.peakDepth) {
-                float resE = eCoef * powf(lp.peakDepth - 0.5f * (cumulSp + cumulSpOld), pInv);
+                // the reference calls __powf (kernel_wrapper.cu:282) = 2^(y*log2(x)) on the special-function unit; same form here
+                float resE = eCoef * __builtin_amdgcn_exp2f(pInv * __builtin_amdgcn_logf(lp.peakDepth - 0.5f * (cumulSp + cumulSpOld)));
                 float betaP = resE + 938.3f - 938.3f * 938.3f / (resE + 938.3f);
                 float rRl = density * (LDS_LUT ? sample1dClamp(sRrl, lut.nRrl, density * fg.rRlScale)
                                                : sample1dClamp(lut.rrl, lut.nRrl, density * fg.rRlScale));
@@ -452,10 +453,12 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
             } else {
                 sigmaSq -= 1.5f * (incScat + incDiv) * density;
             }
-            Vec2 vw = fg.voxelWidth(stepNo);
-            rSigmaEff = 0.5f * (vw.x + vw.y) / (sqrt2 * (sqrtf(sigmaSq) + sigmaDelta));
+            // stepTab[2k] = 0.5*(voxelWidth(k).x + voxelWidth(k).y), stepTab[2k+1] = stepVol(k): per-step constants evaluated once
+            // on the host with the reference's expressions (fill_idd_and_sigma_params.cu:42-46,72)
+            rSigmaEff = stepTab[2 * stepNo] / (sqrt2 * (sqrtf(sigmaSq) + sigmaDelta));
             if (cumulSp > lp.peakDepth * fc.bpDepthCutoff || stepNo == afterLast) { beamLive = false; afterLast = stepNo; }
-            float mass = fc.doseToWater ? (cumulSp - cumulSpOld) * fg.stepVol(stepNo) : density * fg.stepVol(stepNo);
+            const float stepVol = stepTab[2 * stepNo + 1];
+            float mass = fc.doseToWater ? (cumulSp - cumulSpOld) * stepVol : density * stepVol;
             if (mass > 1e-2f) res = rayWeight * (cumulDose - cumulDoseOld) / mass;
             cumulSpOld = cumulSp;
             cumulDoseOld = cumulDose;
