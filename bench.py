@@ -135,7 +135,7 @@ def main():
         info["_steps"] = beam.tracerSteps
         stage_ms = {k: buckets[k] / args.steps for k in buckets if k.endswith("_ms")}
         alg = algorithmic_bytes(info, scn.dims)
-        ks_ms = stage_ms["superp_ms"]
+        ks_ms = stage_ms["superp_kernel_ms"]
         ks_gbs = alg["superposition"] / (ks_ms * 1e-3) / 1e9 if ks_ms > 0 else 0.0
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
@@ -161,10 +161,11 @@ def main():
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "algorithmic_bytes": alg,
             "path_gbs": round(alg["total"] / (stage_ms["total_ms"] * 1e-3) / 1e9, 2),
-            "roofline": {"kernel": "k_superpose", "bound": "hbm", "achieved": round(ks_gbs, 2), "peak": HBM_PEAK_GBS,
+            "roofline": {"kernel": "rtd::k_superpose_mfma", "bound": "hbm", "achieved": round(ks_gbs, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ks_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "avg_launch_ms": round(ks_ms, 4), "algorithmic_bytes_per_launch": alg["superposition"],
-                         "note": "superposition is LDS/VALU-bound, not HBM-bound (SURVEY.md §7); HBM fraction reported as the contract asks"},
+                         "note": "algorithmic bytes = SURVEY.md 8(d) superposition term 8*(R+P)*sum(A_l); the kernel is instruction-issue bound "
+                                 "(operand fetch around f32 MFMA), not HBM-bound; traffic = (2*FETCH_SIZE+WRITE_SIZE)*1024 from profiles/traffic.json"},
         }
         if not args.no_cpu and world == 1:
             from oracle import oracle

@@ -116,7 +116,8 @@ typedef struct rtd_timing {
     float transforming_ms;        /* "Kernel time to transform ... voxels"       */
     float total_ms;               /* first kernel to last kernel of the field    */
     int32_t superp_launches;      /* number of superposition kernel launches     */
-    int32_t reserved[3];
+    float superp_kernel_ms;       /* the dominant kernel alone (k_superpose_mfma), inside superp_ms */
+    int32_t reserved[2];
 } rtd_timing;
 
 /* Geometry and cut-off scalars of the last computed field (for logs, tests and the roofline model). */

@@ -66,7 +66,7 @@ class RtdTiming(C.Structure):
     _fields_ = [
         ("raytracing_ms", C.c_float), ("prepare_energy_loop_ms", C.c_float), ("fill_idd_sigma_ms", C.c_float),
         ("prepare_superp_ms", C.c_float), ("superp_ms", C.c_float), ("transforming_ms", C.c_float),
-        ("total_ms", C.c_float), ("superp_launches", C.c_int32), ("reserved", C.c_int32 * 3),
+        ("total_ms", C.c_float), ("superp_launches", C.c_int32), ("superp_kernel_ms", C.c_float), ("reserved", C.c_int32 * 2),
     ]
 
     def as_dict(self):

@@ -481,6 +481,7 @@ int rtd_field_compute(rtd_handle hh, rtd_field ff, float* dev_dose) {
         const int G = f->ksGroups;
         const int nItems = fc.S * G * nTY * nTX;
         k_superpose_mfma<<<nItems, 64, 0, s>>>(f->dIdd, f->dRSigma, f->dBevPart, f->dTileRad, f->dLayers, f->dState, fc, nTX, nTY, G);
+        if (timing) RTD_HIP(h, hipEventRecord(f->ev[7], s));
         k_superpose_reduce<<<1024, 256, 0, s>>>(f->dBevPart, f->dBev, f->dState, fc, G);
     }
     if (timing) RTD_HIP(h, hipEventRecord(f->ev[5], s));
@@ -510,9 +511,10 @@ int rtd_field_finish(rtd_handle hh, rtd_field ff, rtd_timing* timing, rtd_field_
             RTD_HIP(h, hipEventElapsedTime(&timing->fill_idd_sigma_ms, f->ev[2], f->ev[3]));
             RTD_HIP(h, hipEventElapsedTime(&timing->prepare_superp_ms, f->ev[3], f->ev[4]));
             RTD_HIP(h, hipEventElapsedTime(&timing->superp_ms, f->ev[4], f->ev[5]));
+            RTD_HIP(h, hipEventElapsedTime(&timing->superp_kernel_ms, f->ev[4], f->ev[7]));
             RTD_HIP(h, hipEventElapsedTime(&timing->transforming_ms, f->ev[5], f->ev[6]));
         }
-        timing->superp_launches = 1;
+        timing->superp_launches = 2;   // k_superpose_mfma + k_superpose_reduce (the reference: up to 33 per layer)
     }
     if (info) {
         std::memset(info, 0, sizeof *info);
