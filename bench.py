@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--size", type=int, default=512, help="CT edge in voxels (512 = C3/C4, 768 = C5)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", help="process-group backend; 'gloo' only to rehearse N>1 on a one-GPU box")
     args = ap.parse_args()
 
     import torch
@@ -74,12 +75,16 @@ def main():
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the dose engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()     # one GPU per rank on a real node; shared only in a gloo rehearsal
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=args.backend)
 
     # ---- synthetic inputs (same CT on every rank; field r at gantry angle r*360/world) ----
     n = args.size
@@ -90,7 +95,7 @@ def main():
     beam = scn.beams[rank]
     n_vox = scn.n_voxels
 
-    eng = engine.Engine(local_rank)
+    eng = engine.Engine(dev_index)
     opt = abi.default_options()
     opt.fine_grained_timing = 1
     eng.set_options(opt)
