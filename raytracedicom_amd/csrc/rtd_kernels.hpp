@@ -684,29 +684,40 @@ __global__ __launch_bounds__(64, 6) void k_superpose_mfma(const float* __restric
             // Only quads that carry dose are visited: their lanes are taken from a wave ballot (scalar bit scan), the
             // quad's grid position from the lane that built its first source.
             unsigned long long live = __ballot(dose != 0.0f);
-            const int liA = oy0 + li - 32, liB = li - kq - 32 - cx0;   // lane constants of the A / B table indices
+            // Per-visit address arithmetic is done in LDS byte addresses: operand address = clamp(laneConst + visitScalar,
+            // table centre -4Tm, +4Tm) = one v_add + one v_med3 per operand (the clamp lands on the zero ends of the table
+            // when a tile is out of the source's reach).
+            const int ldsBase = (int)(size_t)(__attribute__((address_space(3))) float*)lds;   // LDS byte address of the slice
+            const int laneTab = ldsBase + (kq * T + Tm) * 4;         // + 16*q*T: centre of the lane's source table
+            const int laneA = laneTab + (oy0 + li - 32) * 4;         // + 64*t - 4*qRow
+            const int laneB = laneTab + (ox0 + li - kq - 32 - cx0) * 4;   // + 64*t - 4*qCol
+            const int laneD = ldsBase + (CS * T + kq) * 4;           // + 16*q: the lane's dose
             while (live) {
-                const int q = (__builtin_ctzll(live)) >> 2;
-                live &= ~(0xFull << (4 * q));
-                const int qRow = __builtin_amdgcn_readlane(sy, 4 * q);
-                const int qCol = __builtin_amdgcn_readlane(sx, 4 * q) - cx0;
-                const float* mq = lds + (4 * q + kq) * T + Tm;
-                // all seven LDS operands are fetched up front (clamped indices hit the zero ends of the table when a tile
-                // is out of the source's reach), then the MFMAs issue back to back under wave-uniform predicates
-                const int iy = liA - qRow, ix = liB - qCol;
-                const float dl = dArr[4 * q + kq];
-                const float e0 = mq[min(max(iy, -Tm), Tm)], e1 = mq[min(max(iy + 16, -Tm), Tm)];
-                const float b0 = mq[min(max(ox0 + ix, -Tm), Tm)], b1 = mq[min(max(ox0 + 16 + ix, -Tm), Tm)];
-                const float b2 = mq[min(max(ox0 + 32 + ix, -Tm), Tm)], b3 = mq[min(max(ox0 + 48 + ix, -Tm), Tm)];
+                const int q4 = __builtin_ctzll(live) & ~3;           // 4*q
+                live &= ~(0xFull << q4);
+                const int qRow = __builtin_amdgcn_readlane(sy, q4);
+                const int qCol = __builtin_amdgcn_readlane(sx, q4) - cx0;
+                const int tabOff = q4 * T * 4;                       // scalar
+                const int ctr = laneTab + tabOff, lo = ctr - 4 * Tm, hi = ctr + 4 * Tm;
+                const int sa = tabOff - 4 * qRow, sb = tabOff - 4 * qCol;
+                int aA[2], aB[4];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) asm("v_med3_i32 %0, %1, %2, %3" : "=v"(aA[t]) : "v"(laneA + 64 * t + sa), "v"(lo), "v"(hi));
+#pragma unroll
+                for (int t = 0; t < 4; ++t) asm("v_med3_i32 %0, %1, %2, %3" : "=v"(aB[t]) : "v"(laneB + 64 * t + sb), "v"(lo), "v"(hi));
+                typedef __attribute__((address_space(3))) const float* lptr;
+                const float dl = *(lptr)(size_t)(laneD + 4 * q4);
+                const float e0 = *(lptr)(size_t)aA[0], e1 = *(lptr)(size_t)aA[1];
+                const float bb[4] = { *(lptr)(size_t)aB[0], *(lptr)(size_t)aB[1], *(lptr)(size_t)aB[2], *(lptr)(size_t)aB[3] };
+                // wave-uniform tile ranges: tiles [tLo, tHi] intersect the quad's band in x, rows yb0 / yb1 in y
                 const int psy = qRow + 32, psx0 = cx0 + qCol + 32;   // padded coordinates of the quad's first source
+                const int tLo = max((psx0 - rho - ox0) >> 4, 0), tHi = min((psx0 + 3 + rho - ox0) >> 4, 3);
                 const bool ya0 = (oy0 <= psy + rho) && (oy0 + 15 >= psy - rho);
                 const bool ya1 = (oy0 + 16 <= psy + rho) && (oy0 + 31 >= psy - rho);
                 const float a0 = dl * e0, a1 = dl * e1;
-                const float bb[4] = {b0, b1, b2, b3};
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const int x0 = ox0 + 16 * t;
-                    if ((x0 <= psx0 + 3 + rho) && (x0 + 15 >= psx0 - rho)) {
+                    if (t >= tLo && t <= tHi) {
                         if (ya0) acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bb[t], acc[0][t], 0, 0, 0);
                         if (ya1) acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bb[t], acc[1][t], 0, 0, 0);
                     }
