@@ -7,7 +7,8 @@ workload N=1: C3 = 512^3 synthetic heterogeneous CT, one field, 10x10 spots x 20
          (BASELINE.json configs[2] — the configuration the metric is quoted on).
          N>1: one field per GPU (gantry angles 360/N apart, same CT replicated), per-rank dose volumes summed into
          rank 0 with one RCCL reduce inside the timed step (weak scaling: per-GPU work fixed).
-step     = rtd_device_zero(dose) + rtd_field_compute (all kernels of the field) [+ dist.reduce] + sync.
+step     = zero the dose volume + rtd_field_compute (all kernels of the field) + rtd_field_finish (sync)
+         [+ N>1: reduce of the union of the fields' bounding boxes into rank 0].
 
 One JSON line on rank 0; `roofline` describes the dominant kernel (kernel superposition) from HIP events recorded
 by the engine on the launch stream during the timed steps; `cpu_baseline` is the CPU oracle timed on this host.
@@ -108,9 +109,13 @@ def main():
     torch.cuda.synchronize()
 
     def step():
+        """One plan iteration: fresh dose volume, all kernels of this rank's field, [reduce of the union bounding box]."""
         dose.zero_()
         fld.compute(dose.data_ptr())
-        plan.reduce_dose(dose, dist)
+        t, info = fld.finish()          # stream sync + per-stage hipEvent times + bounding box of this step
+        if world > 1:
+            plan.reduce_dose_bbox(dose, info["bbox_min"], info["bbox_max"], dist)
+        return t, info
 
     def barrier():
         if world > 1:
@@ -119,13 +124,11 @@ def main():
 
     for _ in range(args.warmup):
         step()
-        fld.finish()
     buckets = {}
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
-        t, info = fld.finish()          # stream sync + per-stage hipEvent times of this step
+        t, info = step()
         for k, v in t.items():
             buckets[k] = buckets.get(k, 0.0) + float(v)
     barrier()
@@ -161,7 +164,7 @@ def main():
                                    "10x10 spots x 20 layers = 2000 spots, 512 tracer steps, 1 mm rays" % (n, world),
                        "ray_grid": info["ray_dims"], "live_steps": info["live_steps"], "max_radius": info["max_radius"],
                        "bbox_voxels": int(np.prod([info["bbox_max"][i] - info["bbox_min"][i] + 1 for i in range(3)])),
-                       "reduce": "rccl reduce(sum) to rank 0" if world > 1 else "none"},
+                       "reduce": "all_gather of 6-int boxes + rccl reduce(sum) of the packed union bounding box to rank 0" if world > 1 else "none"},
             "ms_plan": round(ms_per_step, 4),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "algorithmic_bytes": alg,

@@ -29,3 +29,31 @@ def run_plan(compute_field, n_fields, dose_tensor, dist=None, dst=0):
     for i in shard_fields(n_fields, world, rank):
         compute_field(i)
     return reduce_dose(dose_tensor, dist, dst)
+
+
+def reduce_dose_bbox(dose_tensor, bbox_min, bbox_max, dist=None, dst=0):
+    """Sum only the union of the ranks' dose bounding boxes into rank `dst`.
+
+    Every field writes inside its own bounding box only (kernel_wrapper.cu:1185-1210), so voxels outside the union of
+    the boxes are zero on every rank: exchanging the union box (a 6-int all-gather, then one reduce of the packed box)
+    moves a fraction of the volume over xGMI instead of all of it. dose_tensor is [Z][Y][X]; bbox_* are (x, y, z)
+    inclusive index triples of THIS rank's fields (max < min means "nothing written")."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return dose_tensor
+    import torch
+    world = dist.get_world_size()
+    mine = torch.tensor([int(v) for v in bbox_min] + [int(v) for v in bbox_max], dtype=torch.int64, device=dose_tensor.device)
+    boxes = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(boxes, mine)
+    boxes = torch.stack(boxes).cpu()
+    valid = (boxes[:, 3:] >= boxes[:, :3]).all(dim=1)
+    if not bool(valid.any()):
+        return dose_tensor
+    lo = boxes[valid, :3].min(dim=0).values.tolist()
+    hi = boxes[valid, 3:].max(dim=0).values.tolist()
+    view = dose_tensor[lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1]
+    packed = view.contiguous()
+    dist.reduce(packed, dst=dst, op=dist.ReduceOp.SUM)
+    if dist.get_rank() == dst:
+        view.copy_(packed)
+    return dose_tensor

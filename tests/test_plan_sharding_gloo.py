@@ -20,7 +20,7 @@ def test_shard_fields():
         plan.shard_fields(4, 2, 2)
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, use_bbox=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch
@@ -35,26 +35,37 @@ def _worker(rank, world, port, out_path):
     dose = np.zeros_like(scn.ct)
     t = torch.from_numpy(dose)
 
+    boxes = []
+
     def compute_field(i):
         f = oracle.run_field(scn, scn.beams[i], dose, keep_layers=False)
         assert f.status == 0
+        boxes.append((f.info["bbox_min"], f.info["bbox_max"]))
         f.close()
 
-    plan.run_plan(compute_field, len(scn.beams), t, dist, dst=0)
+    if use_bbox:
+        for i in plan.shard_fields(len(scn.beams), world, rank):
+            compute_field(i)
+        lo = [min(b[0][a] for b in boxes) for a in range(3)] if boxes else [0, 0, 0]
+        hi = [max(b[1][a] for b in boxes) for a in range(3)] if boxes else [-1, -1, -1]
+        plan.reduce_dose_bbox(t, lo, hi, dist, dst=0)
+    else:
+        plan.run_plan(compute_field, len(scn.beams), t, dist, dst=0)
     if rank == 0:
         np.save(out_path, dose)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_plan_equals_sequential(orc, synth, tmp_path):
+@pytest.mark.parametrize("use_bbox", [False, True])
+def test_two_rank_plan_equals_sequential(orc, synth, tmp_path, use_bbox):
     import torch.multiprocessing as mp
     from raytracedicom_amd import scenarios
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = str(tmp_path / "dose.npy")
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, out, use_bbox), nprocs=2, join=True)
     got = np.load(out)
     ct, _ = scenarios.hetero_phantom(64)
     scn = scenarios.hetero_ct(synth, n=64, spots=4, pitch=8.0, n_layers=2, angles=[0.0, 90.0], ct=ct)
