@@ -44,7 +44,7 @@ def algorithmic_bytes(info, dims):
     vbb = bb[0] * bb[1] * bb[2]
     n = dims[0] * dims[1] * dims[2]
     out = {
-        "tracer": 4 * min(n, info.get("_ct_footprint", n)) + 8 * R * S + 8 * R + 4 * R * S,   # CT + density,WEPL + 2 int maps + min-WEPL read
+        "tracer": 4 * min(n, info.get("_ct_footprint", 8 * R * S)) + 8 * R * S + 8 * R + 4 * R * S,   # CT + density,WEPL + 2 int maps + min-WEPL read
         "fill": 16 * R * SA + 4 * R * L + 4 * R * SA,                                       # read rho,WEPL; write idd,1/sigma; weights; tile radius
         "superposition": 8 * R * SA + 8 * P * SA,                                           # read idd,1/sigma; RMW padded BEV
         "bev_zero_read": 4 * P * S + 4 * P * Z,

@@ -118,6 +118,11 @@ def gamma_pass_rate(ref, ev, spacing, dd=0.01, dta=1.0, threshold=0.10):
     return float(r), int(n.value), float(g.value)
 
 
+def set_weight_bits(bits):
+    """0 = exact float interpolation weights (default); 8 = emulate the CUDA texture unit's 8-bit weights."""
+    lib().orc_set_weight_bits(int(bits))
+
+
 def set_threads(n):
     lib().orc_set_threads(int(n))
 

@@ -184,7 +184,18 @@ float orc_vector_interpolate(const float* list, int n, float idx) { /* vector_in
 /* ------------------------------------------------------------------------------------------ */
 /* Samplers: software image of the texture fetches.                                           */
 
-static inline float lerp_w(float a, float v0, float v1) { return (1.0f - a) * v0 + a * v1; }
+/* Optional emulation of the texture unit's fixed-point interpolation weights: CUDA stores the fractional position in
+ * 9-bit fixed point with 8 fractional bits (CUDA C Programming Guide, "Linear Filtering"). 0 = exact float weights
+ * (default, what the HIP engine implements); 8 = weights rounded to 1/256. Used only to QUANTIFY how far a real run
+ * of the reference on NVIDIA hardware is expected to sit from the float-exact restatement. */
+static int g_weight_bits = 0;
+void orc_set_weight_bits(int bits) { g_weight_bits = bits; }
+static inline float quant_w(float a) {
+    if (g_weight_bits <= 0) return a;
+    const float q = (float)(1 << g_weight_bits);
+    return floorf(a * q + 0.5f) / q;
+}
+static inline float lerp_w(float a, float v0, float v1) { a = quant_w(a); return (1.0f - a) * v0 + a * v1; }
 
 /* tex1D, linear, CLAMP (kernel_wrapper.cu:476-537). p = coordinate without the +0.5. */
 static inline float sample1d_clamp(const float* t, int n, float p) {

@@ -13,6 +13,7 @@ extern "C" {
 typedef struct orc_field_s* orc_field;
 
 void orc_set_threads(int n);
+void orc_set_weight_bits(int bits);
 int orc_get_max_threads(void);
 
 /* host helpers (vector_find.h, vector_interpolate.h) */
