@@ -641,16 +641,19 @@ __global__ __launch_bounds__(64, 6) void k_superpose_mfma(const float* __restric
         // span several source rows and every lane builds one table.
         const int nCols = ((cx1 - cx0 + 3) >> 2) << 2;
         const int nSrc = (ry1 - ry0) * nCols;
+        // lane's source position, advanced incrementally from chunk to chunk (no per-chunk division)
+        int sy, sx;
+        {
+            const int r = lane / nCols;
+            sy = ry0 + r; sx = cx0 + (lane - r * nCols);
+        }
+        const int xEnd = cx0 + nCols;
         for (int s0 = 0; s0 < nSrc; s0 += CS) {
             // ---- build: weight table of one source per lane ----
             float dose = 0.0f;
-            int sIdx = s0 + lane, sy = 0, sx = 0;
-            const bool inChunk = lane < CS && sIdx < nSrc;
-            if (inChunk) {
-                const int r = sIdx / nCols;
-                sy = ry0 + r; sx = cx0 + (sIdx - r * nCols);
-                if (sx < cx1) dose = bevIdd[sliceOff + (size_t)sy * W + sx];
-            }
+            if (s0 > 0) { sx += CS; while (sx >= xEnd) { sx -= nCols; ++sy; } }
+            const bool inChunk = lane < CS && s0 + lane < nSrc;
+            if (inChunk && sx < cx1) dose = bevIdd[sliceOff + (size_t)sy * W + sx];
             if (!__any(dose != 0.0f)) continue;                      // chunk carries no dose: contributes exact zeros
             __builtin_amdgcn_wave_barrier();
             if (lane < CS) {
@@ -666,6 +669,8 @@ __global__ __launch_bounds__(64, 6) void k_superpose_mfma(const float* __restric
                 float* m = lds + lane * T;
                 float erfNew = 0.0f, erfOld = 0.0f;
                 if (rhoS >= 0) { erfNew = erff(rs * 0.5f); erfOld = -erfNew; }
+                float* mp = m + Tm;
+                float* mn = m + Tm;
                 for (int i = 0; i <= Tm; ++i) {
                     float e = 0.0f;
                     if (i <= rhoS) {
@@ -673,8 +678,8 @@ __global__ __launch_bounds__(64, 6) void k_superpose_mfma(const float* __restric
                         erfOld = erfNew;
                         erfNew = erff(rs * ((float)i + 1.5f));
                     }
-                    m[Tm + i] = e;
-                    m[Tm - i] = e;
+                    *mp++ = e;
+                    *mn-- = e;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
