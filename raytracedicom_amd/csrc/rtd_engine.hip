@@ -61,6 +61,7 @@ struct rtd_field_impl {
     unsigned char* dTileRad = nullptr;
     LayerPlan* dLayers = nullptr;
     float* dStepTab = nullptr;
+    int* dActive = nullptr;      // [L][S][4] minima of (x, y, -x, -y) over rays with dose > 0
     FieldState* dState = nullptr;
     std::vector<LayerPlan> hLayers;
     hipEvent_t ev[8] = {};
@@ -319,7 +320,7 @@ int rtd_field_destroy(rtd_handle hh, rtd_field ff) {
     (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = { f->dSpotWeights, f->dConvInterm, f->dRayWeights, f->dDensity, f->dWepl, f->dIdd, f->dRSigma, f->dBev, f->dBevPart,
                      f->dFirstInside, f->dFirstOutside, f->dFirstPassive, f->dWeplMin, f->dTileRad,
-                     f->dLayers, f->dState, f->dStepTab };
+                     f->dLayers, f->dState, f->dStepTab, f->dActive };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : f->ev) if (e) (void)hipEventDestroy(e);
     delete f;
@@ -413,7 +414,7 @@ int rtd_field_create(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dims[
     A(&f->dSpotWeights, nSpot); A(&f->dConvInterm, (size_t)W * b->spot_ny * L); A(&f->dRayWeights, R * L);
     A(&f->dDensity, R * S); A(&f->dWepl, R * S); A(&f->dIdd, R * S * L); A(&f->dRSigma, R * S * L); A(&f->dBev, P * S); A(&f->dBevPart, P * S * f->ksGroups);
     A(&f->dFirstInside, R); A(&f->dFirstOutside, R); A(&f->dFirstPassive, R * L); A(&f->dWeplMin, (size_t)S);
-    A(&f->dTileRad, (size_t)L * S * tilesX * tilesY); A(&f->dLayers, (size_t)L); A(&f->dState, (size_t)1); A(&f->dStepTab, (size_t)2 * S);
+    A(&f->dTileRad, (size_t)L * S * tilesX * tilesY); A(&f->dLayers, (size_t)L); A(&f->dState, (size_t)1); A(&f->dStepTab, (size_t)2 * S); A(&f->dActive, (size_t)4 * L * S);
     if (st != RTD_OK) { rtd_field_destroy(hh, reinterpret_cast<rtd_field>(f)); return st; }
     hipError_t e = hipMemcpy(f->dSpotWeights, b->spot_weights, nSpot * sizeof(float), hipMemcpyHostToDevice);   // :851
     if (e == hipSuccess) e = hipMemcpy(f->dLayers, f->hLayers.data(), (size_t)L * sizeof(LayerPlan), hipMemcpyHostToDevice);
@@ -459,6 +460,7 @@ int rtd_field_compute(rtd_handle hh, rtd_field ff, float* dev_dose) {
     if (timing) RTD_HIP(h, hipEventRecord(f->ev[1], s));
     k_plan<<<1, 64, 0, s>>>(f->dState, f->dLayers, f->dWeplMin, fc);
     RTD_HIP(h, hipMemsetAsync(f->dTileRad, kNoRadius, (size_t)fc.L * fc.S * fc.tilesX * fc.tilesY, s));
+    RTD_HIP(h, hipMemsetAsync(f->dActive, 0x7f, (size_t)4 * fc.L * fc.S * sizeof(int), s));   // +large: empty rectangles
     k_conv_x<<<dim3(fc.W / 32, (fc.spotNy + 7) / 8, fc.L), blk, 0, s>>>(f->dSpotWeights, f->dConvInterm, f->dLayers, f->dState, fc);
     k_conv_y<<<dim3(fc.W / 32, fc.H / 8, fc.L), blk, 0, s>>>(f->dConvInterm, f->dRayWeights, f->dLayers, f->dState, fc);
     if (timing) RTD_HIP(h, hipEventRecord(f->ev[2], s));
@@ -467,10 +469,10 @@ int rtd_field_compute(rtd_handle hh, rtd_field ff, float* dev_dose) {
         const dim3 fillGrid(rayGrid.x, rayGrid.y, fc.L);
         if (fillLds <= 96 * 1024)
             k_fill<true><<<fillGrid, blk, fillLds, s>>>(f->dDensity, f->dWepl, f->dIdd, f->dRSigma, f->dRayWeights, f->dFirstInside, f->dFirstOutside,
-                                                        f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc, f->dStepTab);
+                                                        f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc, f->dStepTab, f->dActive);
         else
             k_fill<false><<<fillGrid, blk, 0, s>>>(f->dDensity, f->dWepl, f->dIdd, f->dRSigma, f->dRayWeights, f->dFirstInside, f->dFirstOutside,
-                                                   f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc, f->dStepTab);
+                                                   f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc, f->dStepTab, f->dActive);
     }
     if (timing) RTD_HIP(h, hipEventRecord(f->ev[3], s));
     k_ks_plan<<<1, 64, 0, s>>>(f->dState, f->dLayers, fc, f->rayIdxToDoseIdx, f->transfer0, (int)f->doseDims[0], (int)f->doseDims[1],
@@ -480,7 +482,7 @@ int rtd_field_compute(rtd_handle hh, rtd_field ff, float* dev_dose) {
         const int nTX = (fc.bevW + kKsTileX - 1) / kKsTileX, nTY = (fc.bevH + kKsTileY - 1) / kKsTileY;
         const int G = f->ksGroups;
         const int nItems = fc.S * G * nTY * nTX;
-        k_superpose_mfma<<<nItems, 64, 0, s>>>(f->dIdd, f->dRSigma, f->dBevPart, f->dTileRad, f->dLayers, f->dState, fc, nTX, nTY, G);
+        k_superpose_mfma<<<nItems, 64, 0, s>>>(f->dIdd, f->dRSigma, f->dBevPart, f->dTileRad, f->dLayers, f->dState, fc, nTX, nTY, G, f->dActive);
         if (timing) RTD_HIP(h, hipEventRecord(f->ev[7], s));
         k_superpose_reduce<<<1024, 256, 0, s>>>(f->dBevPart, f->dBev, f->dState, fc, G);
     }

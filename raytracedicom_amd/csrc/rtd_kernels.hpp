@@ -353,9 +353,11 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
                                                const float* __restrict__ rayWeights, const int* __restrict__ firstInside,
                                                const int* __restrict__ firstOutside, int* __restrict__ firstPassive,
                                                unsigned char* __restrict__ tileRad, LayerPlan* layers, FieldState* st,
-                                               LutView lut, FillGeom fg, FieldConst fc, const float* __restrict__ stepTab) {
+                                               LutView lut, FillGeom fg, FieldConst fc, const float* __restrict__ stepTab,
+                                               int* __restrict__ active) {
     extern __shared__ float sLutF[];
     __shared__ float sMin[8][4];
+    __shared__ int sAct[8][4][4];
     __shared__ int sHist[kMaxSuperpR + 2];
 
     const int layer = blockIdx.z;
@@ -414,6 +416,7 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
     constexpr int kFillBatch = 8;   // WEPL/density of a batch of steps are loaded up front (independent of the recurrence)
     for (unsigned int step0 = pFirst; step0 < pAfterLast; step0 += kFillBatch) {
       float spB[kFillBatch], denB[kFillBatch], rsB[kFillBatch];
+      unsigned long long doseMask[kFillBatch];
 #pragma unroll
       for (int j = 0; j < kFillBatch; ++j) {
           const bool in = step0 + j < pAfterLast;
@@ -424,6 +427,7 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
       for (int j = 0; j < kFillBatch; ++j) {
         const unsigned int stepNo = step0 + j;
         rsB[j] = __int_as_float(0x7f800000);
+        doseMask[j] = 0ull;
         if (stepNo >= pAfterLast) continue;                          // block-uniform
         const float curSp = spB[j], curDensity = denB[j];
         if (beamLive) {
@@ -468,6 +472,7 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
         bevRSigmaEff[layerOff + idx] = rSigmaEff;
 
         rsB[j] = rSigmaEff;
+        doseMask[j] = __ballot(res > 0.0f);
         idx += memStep;
       }
       // fused tileRadCalc: min of 1/sigma over the 32x8 tile -> radius class of every (layer, step, tile) of the batch;
@@ -475,7 +480,17 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
 #pragma unroll
       for (int j = 0; j < kFillBatch; ++j) {
           float wm = waveMin(rsB[j]);
-          if ((tid & (kWave - 1)) == 0) sMin[j][wave] = wm;
+          if ((tid & (kWave - 1)) == 0) {
+              sMin[j][wave] = wm;
+              // rectangle of this wave's rays that carry dose at step j (the wave holds rows 2*wave, 2*wave+1 of the tile);
+              // stored as minima of (x, y, -x, -y)
+              const unsigned int lo = (unsigned int)doseMask[j], hi = (unsigned int)(doseMask[j] >> 32), m32 = lo | hi;
+              const int x0t = blockIdx.x * kSuperpTileX, y0w = blockIdx.y * kSuperpTileY + 2 * wave;
+              sAct[j][wave][0] = m32 ? x0t + __builtin_ctz(m32) : 0x7fffffff;
+              sAct[j][wave][1] = m32 ? y0w + (lo ? 0 : 1) : 0x7fffffff;
+              sAct[j][wave][2] = m32 ? -(x0t + 31 - __builtin_clz(m32)) : 0x7fffffff;
+              sAct[j][wave][3] = m32 ? -(y0w + (hi ? 1 : 0)) : 0x7fffffff;
+          }
       }
       __syncthreads();
       if (tid < kFillBatch && step0 + tid < pAfterLast) {
@@ -486,6 +501,11 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
           rad = rad < 0 ? 0 : rad;
           tileRad[((size_t)layer * fc.S + step0 + tid) * nTiles + tileNo] = (unsigned char)rad;
           atomicAdd(&sHist[rad], 1);
+      }
+      if (tid >= 32 && tid < 32 + 4 * kFillBatch) {                  // 4 lanes per step of the batch: one component each
+          const int j = (tid - 32) >> 2, c = (tid - 32) & 3;
+          const int v = min(min(sAct[j][0][c], sAct[j][1][c]), min(sAct[j][2][c], sAct[j][3][c]));
+          if (step0 + j < pAfterLast && v != 0x7fffffff) atomicMin(&active[((size_t)layer * fc.S + step0 + j) * 4 + c], v);
       }
       __syncthreads();
     }
@@ -582,7 +602,7 @@ __device__ inline int clampI(int v, int lo, int hi) { return v < lo ? lo : (v > 
 __global__ __launch_bounds__(64, 6) void k_superpose_mfma(const float* __restrict__ bevIdd, const float* __restrict__ bevRSigmaEff,
                                                             float* __restrict__ bevPart, const unsigned char* __restrict__ tileRad,
                                                             const LayerPlan* __restrict__ layers, const FieldState* __restrict__ st,
-                                                            FieldConst fc, int nTX, int nTY, int G) {
+                                                            FieldConst fc, int nTX, int nTY, int G, const int* __restrict__ active) {
     __shared__ float lds[kKsWaveLds];
     const int lane = threadIdx.x;
     // One wave per block: a heavy item never keeps three finished neighbours' LDS and wave slots occupied.
@@ -630,8 +650,11 @@ __global__ __launch_bounds__(64, 6) void k_superpose_mfma(const float* __restric
         }
         if (rho < 0) continue;                                       // wave-uniform
         const int Tm = rho + 1, T = 2 * Tm + 1;                      // mirrored table m[u], u = d + Tm, d in [-Tm, Tm]; m[+-Tm] = 0
-        const int cx0 = max(ox0 - 32 - rho, 0), cx1 = min(ox0 + 31 + rho + 1, W);
-        const int ry0 = max(oy0 - 32 - rho, 0), ry1 = min(oy0 - 1 + rho + 1, H);
+        // source window = reach of the tile, clipped to the ray grid and to the rectangle of rays that carry dose at this
+        // (layer, step) (recorded by k_fill): margins of dead rays are never scanned
+        const int* act = active + ((size_t)layer * fc.S + k) * 4;
+        const int cx0 = max(max(ox0 - 32 - rho, 0), act[0]), cx1 = min(min(ox0 + 31 + rho + 1, W), -act[2] + 1);
+        const int ry0 = max(max(oy0 - 32 - rho, 0), act[1]), ry1 = min(min(oy0 - 1 + rho + 1, H), -act[3] + 1);
         if (cx1 <= cx0 || ry1 <= ry0) continue;
         const int CS = min(kWave, (kKsWaveLds / (T + 1)) & ~3);      // sources per chunk (whole quads)
         float* dArr = lds + CS * T;
