@@ -66,7 +66,7 @@ struct rtd_field_impl {
     std::vector<LayerPlan> hLayers;
     hipEvent_t ev[8] = {};
     bool computed = false;
-    int ksGroups = 10;   // layer groups of the superposition (partial BEV buffers); RTD_KS_GROUPS overrides
+    int ksGroups = 20;   // layer groups of the superposition (partial BEV buffers); RTD_KS_GROUPS overrides
 };
 
 #define RTD_HIP(h, call)                                                                         \
