@@ -52,6 +52,8 @@ struct FieldState {
     int bboxMin[3], bboxMax[3];     // :1207-1208
     TransferParams transfer;        // :1213
     int empty;                      // nothing inside the patient for this beam
+    int actUnion[4];                // minima of (x, y, -x, -y) over all rays that carry dose in any (layer, step)
+    int bevLo[2], bevHi[2];         // padded-BEV rectangle outside which every slice is exactly zero (transfer early-out)
 };
 
 // Host-known per-field constants, passed by value.
@@ -144,6 +146,7 @@ __global__ void k_reset(FieldState* st, LayerPlan* layers, int L) {
         st->beamFirstInside = 0x7fffffff; st->beamFirstOutside = -0x7fffffff; st->firstGuaranteedPassive = 0;
         st->firstCalculatedPassive = 0; st->errorFlags = 0; st->maxRadius = 0; st->liveSteps = 0;
         st->empty = 0;
+        for (int i = 0; i < 4; ++i) st->actUnion[i] = 0x7fffffff;
         for (int i = 0; i < 3; ++i) { st->bboxMin[i] = 0; st->bboxMax[i] = 0; }
     }
     for (int l = t; l < L; l += gridDim.x * blockDim.x) {
@@ -413,6 +416,7 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
     __syncthreads();
 
     idx += (size_t)pFirst * memStep;
+    int actUni = 0x7fffffff;
     constexpr int kFillBatch = 8;   // WEPL/density of a batch of steps are loaded up front (independent of the recurrence)
     for (unsigned int step0 = pFirst; step0 < pAfterLast; step0 += kFillBatch) {
       float spB[kFillBatch], denB[kFillBatch], rsB[kFillBatch];
@@ -505,7 +509,7 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
       if (tid >= 32 && tid < 32 + 4 * kFillBatch) {                  // 4 lanes per step of the batch: one component each
           const int j = (tid - 32) >> 2, c = (tid - 32) & 3;
           const int v = min(min(sAct[j][0][c], sAct[j][1][c]), min(sAct[j][2][c], sAct[j][3][c]));
-          if (step0 + j < pAfterLast && v != 0x7fffffff) atomicMin(&active[((size_t)layer * fc.S + step0 + j) * 4 + c], v);
+          if (step0 + j < pAfterLast && v != 0x7fffffff) { atomicMin(&active[((size_t)layer * fc.S + step0 + j) * 4 + c], v); actUni = min(actUni, v); }
       }
       __syncthreads();
     }
@@ -514,6 +518,7 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
     if ((tid & (kWave - 1)) == 0) atomicMax(&layers[layer].layerFirstPassive, mx);
     __syncthreads();
     if (tid < kMaxSuperpR + 2 && sHist[tid] > 0) atomicAdd(&layers[layer].hist[tid], sHist[tid]);
+    if (tid >= 32 && tid < 32 + 4 * kFillBatch && actUni != 0x7fffffff) atomicMin(&st->actUnion[(tid - 32) & 3], actUni);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -551,6 +556,10 @@ __global__ void k_ks_plan(FieldState* st, LayerPlan* layers, FieldConst fc, From
         const int calcPassive = sMaxPassive;
         st->firstCalculatedPassive = calcPassive;
         st->maxRadius = sMaxRad;
+        // a source at ray (x, y) reaches padded BEV pixels (x+32 +- r, y+32 +- r), r <= the largest batch radius
+        const int rr = min(sMaxRad, kMaxSuperpR);
+        st->bevLo[0] = st->actUnion[0] + 32 - rr; st->bevLo[1] = st->actUnion[1] + 32 - rr;
+        st->bevHi[0] = -st->actUnion[2] + 32 + rr; st->bevHi[1] = -st->actUnion[3] + 32 + rr;
         st->liveSteps = (long long)sLive;
         TransferParams tp = tp0;
         tp.globalOffset.z = tp0.globalOffset.z + (-(float)first);   // invertAndShift(..., -beamFirstInside) :1213
@@ -806,9 +815,13 @@ __global__ __launch_bounds__(256) void k_transfer(float* __restrict__ dose, int 
     p.init(x, y);
     const float* slab = bevDose + (size_t)first * fc.bevW * fc.bevH;
     float* res = dose + (size_t)z0 * nx * ny + (size_t)y * nx + x;
+    // outside this rectangle (+1 for the interpolation neighbours) every BEV slice is exactly zero: no loads needed
+    const float exLo = (float)(st->bevLo[0] - 1), exHi = (float)(st->bevHi[0] + 1), eyLo = (float)(st->bevLo[1] - 1), eyHi = (float)(st->bevHi[1] + 1);
     for (int z = z0; z <= z1; ++z) {
         Vec3 pos = p.getFanIdx(z);
-        float tmp = sample3dBorder(slab, fc.bevW, fc.bevH, slabZ, pos.x, pos.y, pos.z);
+        float tmp = 0.0f;
+        if (pos.x > exLo && pos.x < exHi && pos.y > eyLo && pos.y < eyHi)
+            tmp = sample3dBorder(slab, fc.bevW, fc.bevH, slabZ, pos.x, pos.y, pos.z);
         if (tmp > 0.0f) *res += tmp;
         res += (size_t)nx * ny;
     }
