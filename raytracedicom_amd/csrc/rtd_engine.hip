@@ -476,7 +476,7 @@ int rtd_field_compute(rtd_handle hh, rtd_field ff, float* dev_dose) {
     }
     if (timing) RTD_HIP(h, hipEventRecord(f->ev[3], s));
     k_ks_plan<<<1, 64, 0, s>>>(f->dState, f->dLayers, fc, f->rayIdxToDoseIdx, f->transfer0, (int)f->doseDims[0], (int)f->doseDims[1],
-                               (int)f->doseDims[2]);
+                               (int)f->doseDims[2], f->ksGroups);
     if (timing) RTD_HIP(h, hipEventRecord(f->ev[4], s));
     {
         const int nTX = (fc.bevW + kKsTileX - 1) / kKsTileX, nTY = (fc.bevH + kKsTileY - 1) / kKsTileY;

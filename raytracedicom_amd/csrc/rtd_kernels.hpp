@@ -52,6 +52,7 @@ struct FieldState {
     int bboxMin[3], bboxMax[3];     // :1207-1208
     TransferParams transfer;        // :1213
     int empty;                      // nothing inside the patient for this beam
+    int groupPassive[32];           // per superposition layer group: first step at which none of its layers deposits
     int actUnion[4];                // minima of (x, y, -x, -y) over all rays that carry dose in any (layer, step)
     int bevLo[2], bevHi[2];         // padded-BEV rectangle outside which every slice is exactly zero (transfer early-out)
 };
@@ -525,11 +526,13 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
 // K6: superposition plan = host batching of radii (kernel_wrapper.cu:965-976) + beamFirstCalculatedPassive
 // (:955-957) + transfer bounding box and shift (:1185-1213), all on the device.
 __global__ void k_ks_plan(FieldState* st, LayerPlan* layers, FieldConst fc, FromFan rayIdxToDoseIdx, TransferParams tp0,
-                          int doseNx, int doseNy, int doseNz) {
+                          int doseNx, int doseNy, int doseNz, int G) {
     __shared__ int sMaxPassive;
+    __shared__ int sGroup[32];
     __shared__ int sMaxRad;
     __shared__ unsigned long long sLive;
     if (threadIdx.x == 0) { sMaxPassive = 0; sMaxRad = 0; sLive = 0ull; }
+    if (threadIdx.x < 32) sGroup[threadIdx.x] = 0;
     __syncthreads();
     const int first = st->beamFirstInside;
     for (int l = threadIdx.x; l < fc.L; l += blockDim.x) {
@@ -549,6 +552,7 @@ __global__ void k_ks_plan(FieldState* st, LayerPlan* layers, FieldConst fc, From
         }
         atomicMax(&sMaxRad, layerMax);
         atomicMax(&sMaxPassive, p.layerFirstPassive);
+        atomicMax(&sGroup[l % G], p.layerFirstPassive);
         if (p.layerFirstPassive > first) atomicAdd(&sLive, (unsigned long long)(p.layerFirstPassive - first));
     }
     __syncthreads();
@@ -556,6 +560,7 @@ __global__ void k_ks_plan(FieldState* st, LayerPlan* layers, FieldConst fc, From
         const int calcPassive = sMaxPassive;
         st->firstCalculatedPassive = calcPassive;
         st->maxRadius = sMaxRad;
+        for (int gI = 0; gI < 32; ++gI) st->groupPassive[gI] = sGroup[gI];
         // a source at ray (x, y) reaches padded BEV pixels (x+32 +- r, y+32 +- r), r <= the largest batch radius
         const int rr = min(sMaxRad, kMaxSuperpR);
         st->bevLo[0] = st->actUnion[0] + 32 - rr; st->bevLo[1] = st->actUnion[1] + 32 - rr;
@@ -623,6 +628,7 @@ __global__ __launch_bounds__(64, 6) void k_superpose_mfma(const float* __restric
     const int k = fc.S - 1 - item / G;                                // deepest steps (largest radii, most work) are dispatched first
     const int first = st->beamFirstInside, calcPassive = st->firstCalculatedPassive;
     if (k < 0 || k < first || k >= calcPassive) return;
+    if (k >= st->groupPassive[g]) return;                             // no layer of this group deposits at k: the reduce skips this partial
     const int li = lane & 15, kq = lane >> 4;                         // MFMA 16x16x4: A[i=li][k=kq], B[k=kq][j=li]
     const int ox0 = tX * kKsTileX, oy0 = tY * kKsTileY;               // padded BEV coordinates of the owned tile
     const int W = fc.W, H = fc.H;
@@ -784,9 +790,12 @@ __global__ __launch_bounds__(256) void k_superpose_reduce(const float* __restric
     const float4* p0 = reinterpret_cast<const float4*>(bevPart + (size_t)first * P);
     float4* o = reinterpret_cast<float4*>(bevDose + (size_t)first * P);
     const size_t gstride = (size_t)fc.S * P / 4;
+    const size_t P4 = P / 4;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        float4 a = p0[i];
-        for (int gI = 1; gI < G; ++gI) {
+        const int k = first + (int)(i / P4);
+        float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int gI = 0; gI < G; ++gI) {
+            if (k >= st->groupPassive[gI]) continue;                 // this group's partial slice was not written (all zero)
             const float4 b = p0[i + gI * gstride];
             a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
         }
