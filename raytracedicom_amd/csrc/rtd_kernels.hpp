@@ -451,10 +451,13 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
             if (cumulSp < lp.peakDepth) {
                 // the reference calls __powf (kernel_wrapper.cu:282) = 2^(y*log2(x)) on the special-function unit; same form here
                 float resE = eCoef * __builtin_amdgcn_exp2f(pInv * __builtin_amdgcn_logf(lp.peakDepth - 0.5f * (cumulSp + cumulSpOld)));
-                float betaP = resE + 938.3f - 938.3f * 938.3f / (resE + 938.3f);
+                // divisions and the square root of this kernel use the hardware reciprocal / sqrt (<= 1-2 ulp): the reference is
+                // built with -use_fast_math (CMakeLists.txt:52-55), where they are approximate too; no comparison or
+                // branch below depends on them
+                float betaP = resE + 938.3f - 938.3f * 938.3f * __builtin_amdgcn_rcpf(resE + 938.3f);
                 float rRl = density * (LDS_LUT ? sample1dClamp(sRrl, lut.nRrl, density * fg.rRlScale)
                                                : sample1dClamp(lut.rrl, lut.nRrl, density * fg.rRlScale));
-                float thetaSq = eRefSq / (betaP * betaP) * fg.stepLength * rRl;
+                float thetaSq = eRefSq * __builtin_amdgcn_rcpf(betaP * betaP) * fg.stepLength * rRl;
                 sigmaSq += incScat + incDiv;
                 incincScat += 2.0f * thetaSq * fg.stepLength * fg.stepLength;
                 incScat += incincScat;
@@ -464,11 +467,11 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
             }
             // stepTab[2k] = 0.5*(voxelWidth(k).x + voxelWidth(k).y), stepTab[2k+1] = stepVol(k): per-step constants evaluated once
             // on the host with the reference's expressions (fill_idd_and_sigma_params.cu:42-46,72)
-            rSigmaEff = stepTab[2 * stepNo] / (sqrt2 * (sqrtf(sigmaSq) + sigmaDelta));
+            rSigmaEff = stepTab[2 * stepNo] * __builtin_amdgcn_rcpf(sqrt2 * (__builtin_amdgcn_sqrtf(sigmaSq) + sigmaDelta));
             if (cumulSp > lp.peakDepth * fc.bpDepthCutoff || stepNo == afterLast) { beamLive = false; afterLast = stepNo; }
             const float stepVol = stepTab[2 * stepNo + 1];
             float mass = fc.doseToWater ? (cumulSp - cumulSpOld) * stepVol : density * stepVol;
-            if (mass > 1e-2f) res = rayWeight * (cumulDose - cumulDoseOld) / mass;
+            if (mass > 1e-2f) res = rayWeight * (cumulDose - cumulDoseOld) * __builtin_amdgcn_rcpf(mass);
             cumulSpOld = cumulSp;
             cumulDoseOld = cumulDose;
         }
