@@ -104,26 +104,39 @@ def main():
     eng.set_luts(es)
     ct_dev = torch.from_numpy(ct_np).to(dev)
     eng.set_ct_device(ct_dev.data_ptr(), scn.dims)
-    dose = torch.zeros((n, n, n), dtype=torch.float32, device=dev)
+    # N>1: two alternating dose volumes so that the reduce of plan i (communication stream) overlaps the kernels of plan i+1
+    doses = [torch.zeros((n, n, n), dtype=torch.float32, device=dev) for _ in range(2 if world > 1 else 1)]
+    dose = doses[0]
     fld = eng.create_field(beam, scn.dims)
+    reducer = plan.PipelinedBoxReduce(dist) if world > 1 else None
     torch.cuda.synchronize()
+    step_no = [0]
 
     def step():
-        """One plan iteration: fresh dose volume, all kernels of this rank's field, [reduce of the union bounding box]."""
-        dose.zero_()
-        fld.compute(dose.data_ptr())
+        """One plan iteration: fresh dose volume, all kernels of this rank's field, [N>1: reduce of the union bounding box
+        into rank 0, left in flight while the next plan's kernels run]."""
+        d = doses[step_no[0] % len(doses)]
+        step_no[0] += 1
+        if reducer is not None:
+            reducer.release(d)          # the reduce that used this volume two plans ago has completed
+        d.zero_()
+        fld.compute(d.data_ptr())
         t, info = fld.finish()          # stream sync + per-stage hipEvent times + bounding box of this step
-        if world > 1:
-            plan.reduce_dose_bbox(dose, info["bbox_min"], info["bbox_max"], dist)
+        if reducer is not None:
+            reducer.submit(d, info["bbox_min"], info["bbox_max"])
         return t, info
 
     def barrier():
+        if reducer is not None:
+            reducer.drain()             # every plan's reduce has completed and rank 0 holds the sums
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
+    if reducer is not None:
+        reducer.drain()
     buckets = {}
     barrier()
     t0 = time.perf_counter()
@@ -138,6 +151,22 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     ms_per_step = 1000.0 * elapsed / args.steps
+
+    # N>1 self-check (untimed): the reduced volume on rank 0 must hold the sum of all ranks' fields
+    reduce_check = None
+    if world > 1:
+        d = doses[0]
+        reducer.release(d)
+        d.zero_()
+        fld.compute(d.data_ptr())
+        _, chk_info = fld.finish()
+        local_sum = d.sum(dtype=torch.float64).reshape(1)
+        reducer.submit(d, chk_info["bbox_min"], chk_info["bbox_max"])
+        reducer.drain()
+        dist.all_reduce(local_sum, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            total = float(d.sum(dtype=torch.float64).item())
+            reduce_check = abs(total - float(local_sum.item())) / max(float(local_sum.item()), 1e-300)
 
     if rank == 0:
         info["_steps"] = beam.tracerSteps
@@ -164,8 +193,9 @@ def main():
                                    "10x10 spots x 20 layers = 2000 spots, 512 tracer steps, 1 mm rays" % (n, world),
                        "ray_grid": info["ray_dims"], "live_steps": info["live_steps"], "max_radius": info["max_radius"],
                        "bbox_voxels": int(np.prod([info["bbox_max"][i] - info["bbox_min"][i] + 1 for i in range(3)])),
-                       "reduce": "all_gather of 6-int boxes + rccl reduce(sum) of the packed union bounding box to rank 0" if world > 1 else "none"},
+                       "reduce": "all_gather of 6-int boxes + rccl reduce(sum) of the packed union bounding box to rank 0, overlapped with the next plan" if world > 1 else "none"},
             "ms_plan": round(ms_per_step, 4),
+            "reduce_check_rel_err": reduce_check,
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "algorithmic_bytes": alg,
             "path_gbs": round(alg["total"] / (stage_ms["total_ms"] * 1e-3) / 1e9, 2),

@@ -57,3 +57,53 @@ def reduce_dose_bbox(dose_tensor, bbox_min, bbox_max, dist=None, dst=0):
     if dist.get_rank() == dst:
         view.copy_(packed)
     return dose_tensor
+
+
+class PipelinedBoxReduce:
+    """reduce_dose_bbox with the collective left in flight: step i's packed box is reduced on the communication stream
+    while the kernels of step i+1 run, so a sequence of plans costs max(compute, reduce) per plan instead of their sum.
+
+    Usage per plan step, with `dose` one of two alternating volumes: `release(dose)` BEFORE the volume is zeroed and
+    refilled (it completes the reduce that used this volume two steps earlier and, on the destination rank, stores its
+    sum), then the field's kernels and rtd_field_finish, then `submit(dose, bbox_min, bbox_max)`; `drain()` before the
+    results are read and before the timed region ends."""
+
+    def __init__(self, dist, dst=0):
+        self.dist = dist
+        self.dst = dst
+        self.pending = {}          # id(dose tensor) -> (work, view, packed)
+
+    def _retire(self, key):
+        item = self.pending.pop(key, None)
+        if item is None:
+            return
+        work, view, packed = item
+        work.wait()
+        if self.dist.get_rank() == self.dst:
+            view.copy_(packed)
+
+    def release(self, dose_tensor):
+        self._retire(id(dose_tensor))
+
+    def submit(self, dose_tensor, bbox_min, bbox_max):
+        import torch
+        dist = self.dist
+        assert id(dose_tensor) not in self.pending, "release() the volume before refilling it"
+        world = dist.get_world_size()
+        mine = torch.tensor([int(v) for v in bbox_min] + [int(v) for v in bbox_max], dtype=torch.int64, device=dose_tensor.device)
+        boxes = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(boxes, mine)
+        boxes = torch.stack(boxes).cpu()
+        valid = (boxes[:, 3:] >= boxes[:, :3]).all(dim=1)
+        if not bool(valid.any()):
+            return
+        lo = boxes[valid, :3].min(dim=0).values.tolist()
+        hi = boxes[valid, 3:].max(dim=0).values.tolist()
+        view = dose_tensor[lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1]
+        packed = view.contiguous()
+        work = dist.reduce(packed, dst=self.dst, op=dist.ReduceOp.SUM, async_op=True)
+        self.pending[id(dose_tensor)] = (work, view, packed)
+
+    def drain(self):
+        for key in list(self.pending):
+            self._retire(key)

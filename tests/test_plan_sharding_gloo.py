@@ -43,7 +43,26 @@ def _worker(rank, world, port, out_path, use_bbox=False):
         boxes.append((f.info["bbox_min"], f.info["bbox_max"]))
         f.close()
 
-    if use_bbox:
+    if use_bbox == "pipe":
+        # three plan iterations on two alternating volumes, reduces left in flight (bench.py's N>1 path)
+        red = plan.PipelinedBoxReduce(dist, dst=0)
+        vols = [np.zeros_like(scn.ct), np.zeros_like(scn.ct)]
+        tens = [torch.from_numpy(v) for v in vols]
+        for it in range(3):
+            v = vols[it % 2]
+            red.release(tens[it % 2])
+            v[:] = 0.0
+            bl, bh = [10 ** 9] * 3, [-1] * 3
+            for i in plan.shard_fields(len(scn.beams), world, rank):
+                f = oracle.run_field(scn, scn.beams[i], v, keep_layers=False)
+                bl = [min(a, b) for a, b in zip(bl, f.info["bbox_min"])]
+                bh = [max(a, b) for a, b in zip(bh, f.info["bbox_max"])]
+                f.close()
+            red.submit(tens[it % 2], bl, bh)
+        red.drain()
+        dose[:] = vols[0]            # iteration 2 used volume 0
+        assert np.array_equal(vols[0], vols[1]) or rank != 0   # iteration 1 (volume 1) gives the same sum on rank 0
+    elif use_bbox:
         for i in plan.shard_fields(len(scn.beams), world, rank):
             compute_field(i)
         lo = [min(b[0][a] for b in boxes) for a in range(3)] if boxes else [0, 0, 0]
@@ -57,7 +76,7 @@ def _worker(rank, world, port, out_path, use_bbox=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("use_bbox", [False, True])
+@pytest.mark.parametrize("use_bbox", [False, True, "pipe"])
 def test_two_rank_plan_equals_sequential(orc, synth, tmp_path, use_bbox):
     import torch.multiprocessing as mp
     from raytracedicom_amd import scenarios
