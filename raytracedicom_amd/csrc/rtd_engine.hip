@@ -406,6 +406,11 @@ int rtd_field_create(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dims[
 
     if (const char* v = std::getenv("RTD_KS_GROUPS")) f->ksGroups = std::max(1, std::min(kKsMaxGroups, std::atoi(v)));
     f->ksGroups = std::min(f->ksGroups, L);
+    {   // keep the partial BEV buffers below ~4 GiB for large ray grids (G only trades parallelism for memory)
+        const size_t sliceBytes = (size_t)fc.bevW * fc.bevH * (size_t)S * sizeof(float);
+        const size_t cap = (size_t)4 << 30;
+        f->ksGroups = (int)std::max<size_t>(1, std::min<size_t>((size_t)f->ksGroups, cap / std::max<size_t>(sliceBytes, 1)));
+    }
     // workspace (the reference's per-beam cudaMallocs, :685-734, :804-808)
     const size_t R = f->R, P = (size_t)fc.bevW * fc.bevH;
     const size_t nSpot = (size_t)b->spot_nx * b->spot_ny * L;
