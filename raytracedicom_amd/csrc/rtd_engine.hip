@@ -355,6 +355,7 @@ int rtd_field_create(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dims[
     const Vec3 off = v3(res.x * (float)lSteps, res.y * (float)bSteps, sitg.offset.z);                          // :654
     const int W = roundTo(rSteps - lSteps + 1, kSuperpTileX), H = roundTo(tSteps - bSteps + 1, kSuperpTileY);   // :659
     if (W <= 0 || H <= 0) return fail(h, RTD_ERR_INVALID_ARG, "rtd_field_create: empty ray grid");
+    if (W > 4095 || H > 4095) return fail(h, RTD_ERR_INVALID_ARG, "rtd_field_create: ray grid larger than 4095 x 4095");
     const int tilesX = W / kSuperpTileX, tilesY = H / kSuperpTileY;
     if (L > kMaxLayers || S > kMaxSteps)
         return fail(h, RTD_ERR_INVALID_ARG, "rtd_field_create: more than 256 layers or 4096 steps");
@@ -487,7 +488,7 @@ int rtd_field_compute(rtd_handle hh, rtd_field ff, float* dev_dose) {
         const int nTX = (fc.bevW + kKsTileX - 1) / kKsTileX, nTY = (fc.bevH + kKsTileY - 1) / kKsTileY;
         const int G = f->ksGroups;
         const int nItems = fc.S * G * nTY * nTX;
-        k_superpose_mfma<<<nItems, 64, 0, s>>>(f->dIdd, f->dRSigma, f->dBevPart, f->dTileRad, f->dLayers, f->dState, fc, nTX, nTY, G, f->dActive);
+        k_superpose_mfma<<<nItems, 64 * kKsSplit, 0, s>>>(f->dIdd, f->dRSigma, f->dBevPart, f->dTileRad, f->dLayers, f->dState, fc, nTX, nTY, G, f->dActive);
         if (timing) RTD_HIP(h, hipEventRecord(f->ev[7], s));
         k_superpose_reduce<<<1024, 256, 0, s>>>(f->dBevPart, f->dBev, f->dState, fc, G);
     }

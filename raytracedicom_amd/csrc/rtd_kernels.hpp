@@ -611,17 +611,26 @@ __global__ void k_ks_plan(FieldState* st, LayerPlan* layers, FieldConst fc, From
 // once and k_superpose_reduce adds the G partials in fixed order, so the BEV dose is bitwise reproducible.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kKsTileX = 64, kKsTileY = 32;   // output tile owned by one wave (4 x 2 MFMA tiles)
-constexpr int kKsWaveLds = 1600;              // floats of LDS per wave (10 KiB): tables [CS][T] + doses [CS]
+constexpr int kKsSplit = 1;                   // waves per work item (its source chunks are dealt round-robin to them, accumulators
+                                              // summed through LDS at the end); measured: 2 = no gain, 4 = slower, so 1 (single-wave blocks)
+constexpr int kKsWaveLds = 1200;              // floats of LDS per wave (4.7 KiB): tables [CS][T] + doses [CS]; with the reach table
+                                              // 5 KiB per block, so LDS admits 31 blocks per CU and the 72 VGPRs 7 waves per SIMD
+constexpr int kKsReachTiles = 80;            // 32x8 source tiles within +-32 of a 64x32 output tile: <= 5 x 13
 constexpr int kKsMaxGroups = 32;              // upper bound of layer groups (= partial BEV buffers)
 
 __device__ inline int clampI(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-__global__ __launch_bounds__(64, 6) void k_superpose_mfma(const float* __restrict__ bevIdd, const float* __restrict__ bevRSigmaEff,
+__global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float* __restrict__ bevIdd, const float* __restrict__ bevRSigmaEff,
                                                             float* __restrict__ bevPart, const unsigned char* __restrict__ tileRad,
                                                             const LayerPlan* __restrict__ layers, const FieldState* __restrict__ st,
                                                             FieldConst fc, int nTX, int nTY, int G, const int* __restrict__ active) {
-    __shared__ float lds[kKsWaveLds];
-    const int lane = threadIdx.x;
+    constexpr int kSlice = kKsWaveLds + kKsReachTiles;
+    static_assert(kKsSplit == 1 || kKsSplit * kSlice >= 2048, "the accumulator exchange needs 2048 floats of LDS");
+    __shared__ float ldsAll[kKsSplit * kSlice];
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave of the item (wave-uniform)
+    float* lds = ldsAll + wv * kSlice;                             // this wave's private slice
+    int* effT = reinterpret_cast<int*>(lds + kKsWaveLds);          // batch radius of every source tile in reach (-1: none)
+    const int lane = threadIdx.x & 63;
     // One wave per block: a heavy item never keeps three finished neighbours' LDS and wave slots occupied.
     // decode the work item (wave-uniform): fastest index = tile x, then tile y, then group, then step
     int item = blockIdx.x;
@@ -650,22 +659,21 @@ __global__ __launch_bounds__(64, 6) void k_superpose_mfma(const float* __restric
         const unsigned char* tr = tileRad + ((size_t)layer * fc.S + k) * nTiles;
         // ---- reach: largest batch radius among the 32x8 source tiles whose patches can touch the owned tile ----
         int rho = -1;
-        {
-            // source-coordinate rectangle of the owned tile: [ox0-32, ox0+31] x [oy0-32, oy0-1]
-            const int tx0 = clampI((ox0 - 32 - kMaxSuperpR) >> 5, 0, fc.tilesX - 1), tx1 = clampI((ox0 + 31 + kMaxSuperpR) >> 5, 0, fc.tilesX - 1);
-            const int ty0 = clampI((oy0 - 32 - kMaxSuperpR) >> 3, 0, fc.tilesY - 1), ty1 = clampI((oy0 - 1 + kMaxSuperpR) >> 3, 0, fc.tilesY - 1);
-            const int ntx = tx1 - tx0 + 1, nt = ntx * (ty1 - ty0 + 1);
-            for (int t = lane; t < nt; t += kWave) {
-                const int tx = tx0 + t % ntx, ty = ty0 + t / ntx;
-                const int own = tr[ty * fc.tilesX + tx];
-                if (own > kMaxSuperpR) continue;                     // unclassified (0xFF) or overflow (reported via errorFlags)
-                const int r = eff[own];
-                const int gx = max(max(tx * 32 - (ox0 + 31), (ox0 - 32) - (tx * 32 + 31)), 0);
-                const int gy = max(max(ty * 8 - (oy0 - 1), (oy0 - 32) - (ty * 8 + 7)), 0);
-                if (max(gx, gy) <= r) rho = max(rho, r);
-            }
-            rho = waveMaxI(rho);
+        // source-coordinate rectangle of the owned tile: [ox0-32, ox0+31] x [oy0-32, oy0-1]
+        const int tx0 = clampI((ox0 - 32 - kMaxSuperpR) >> 5, 0, fc.tilesX - 1), tx1 = clampI((ox0 + 31 + kMaxSuperpR) >> 5, 0, fc.tilesX - 1);
+        const int ty0 = clampI((oy0 - 32 - kMaxSuperpR) >> 3, 0, fc.tilesY - 1), ty1 = clampI((oy0 - 1 + kMaxSuperpR) >> 3, 0, fc.tilesY - 1);
+        const int ntx = tx1 - tx0 + 1, nt = ntx * (ty1 - ty0 + 1);   // <= kKsReachTiles
+        __builtin_amdgcn_wave_barrier();
+        for (int t = lane; t < nt; t += kWave) {
+            const int tx = tx0 + t % ntx, ty = ty0 + t / ntx;
+            const int own = tr[ty * fc.tilesX + tx];
+            const int r = own <= kMaxSuperpR ? eff[own] : -1;        // unclassified (0xFF) or overflow (reported via errorFlags)
+            effT[t] = r;
+            const int gx = max(max(tx * 32 - (ox0 + 31), (ox0 - 32) - (tx * 32 + 31)), 0);
+            const int gy = max(max(ty * 8 - (oy0 - 1), (oy0 - 32) - (ty * 8 + 7)), 0);
+            if (max(gx, gy) <= r) rho = max(rho, r);
         }
+        rho = waveMaxI(rho);
         if (rho < 0) continue;                                       // wave-uniform
         const int Tm = rho + 1, T = 2 * Tm + 1;                      // mirrored table m[u], u = d + Tm, d in [-Tm, Tm]; m[+-Tm] = 0
         // source window = reach of the tile, clipped to the ray grid and to the rectangle of rays that carry dose at this
@@ -685,91 +693,176 @@ __global__ __launch_bounds__(64, 6) void k_superpose_mfma(const float* __restric
         // lane's source position, advanced incrementally from chunk to chunk (no per-chunk division)
         int sy, sx;
         {
-            const int r = lane / nCols;
-            sy = ry0 + r; sx = cx0 + (lane - r * nCols);
+            const int i0 = wv * CS + lane, r = i0 / nCols;           // wave wv starts with chunk wv
+            sy = ry0 + r; sx = cx0 + (i0 - r * nCols);
         }
         const int xEnd = cx0 + nCols;
-        for (int s0 = 0; s0 < nSrc; s0 += CS) {
-            // ---- build: weight table of one source per lane ----
-            float dose = 0.0f;
-            if (s0 > 0) { sx += CS; while (sx >= xEnd) { sx -= nCols; ++sy; } }
-            const bool inChunk = lane < CS && s0 + lane < nSrc;
-            if (inChunk && sx < cx1) dose = bevIdd[sliceOff + (size_t)sy * W + sx];
+        // Per-visit address arithmetic is done in LDS byte addresses: operand address = clamp(laneConst + visitScalar,
+        // table centre -4Tm, +4Tm) = one v_add + one v_med3 per operand (the clamp lands on the zero ends of the table
+        // when a lane's row/column is out of the source's reach).
+        const int ldsBase = (int)(size_t)(__attribute__((address_space(3))) float*)lds;   // LDS byte address of the slice
+        const int laneTab = ldsBase + (kq * T + Tm) * 4;             // + 16*q*T: centre of the lane's source table
+        const int laneA = laneTab + (oy0 + li - 32) * 4;             // + 64*t - 4*qRow
+        const int laneB = laneTab + (ox0 + li - kq - 32 - cx0) * 4;  // + 64*t - 4*qCol
+        const int laneD = ldsBase + (CS * T + kq) * 4;               // + 16*q: the lane's dose
+        // dose and 1/sigma of a chunk are fetched one chunk ahead (one memory round trip, hidden behind the previous chunk)
+        const float* __restrict__ iddSlice = bevIdd + sliceOff;
+        const float* __restrict__ rsSlice = bevRSigmaEff + sliceOff;
+        float doseN = 0.0f, rsN = 0.0f;
+        if (lane < CS && wv * CS + lane < nSrc && sx < cx1) {
+            doseN = iddSlice[(unsigned)(sy * W + sx)];
+            rsN = rsSlice[(unsigned)(sy * W + sx)];
+        }
+        int sxN = sx, syN = sy;
+        for (int s0 = wv * CS; s0 < nSrc; s0 += kKsSplit * CS) {
+            float dose = doseN;
+            const float rs = rsN;
+            sx = sxN; sy = syN;
+            doseN = 0.0f; rsN = 0.0f;
+            if (s0 + kKsSplit * CS < nSrc) {
+                sxN += kKsSplit * CS; while (sxN >= xEnd) { sxN -= nCols; ++syN; }
+                if (lane < CS && s0 + kKsSplit * CS + lane < nSrc && sxN < cx1) {
+                    doseN = iddSlice[(unsigned)(syN * W + sxN)];
+                    rsN = rsSlice[(unsigned)(syN * W + sxN)];
+                }
+            }
             if (!__any(dose != 0.0f)) continue;                      // chunk carries no dose: contributes exact zeros
+            // ---- reach masks: which of the 8 output tiles can each source touch with ITS OWN batch radius ----
+            int rhoS = -1, tmask = 0;
+            if (dose != 0.0f) {
+                rhoS = effT[((sy >> 3) - ty0) * ntx + ((sx >> 5) - tx0)];
+                if (rhoS < 0) dose = 0.0f;
+                else {
+                    const int px = sx + 32 - ox0, py = sy + 32 - oy0;        // source position relative to the owned tile
+                    const int tLo = max((px - rhoS) >> 4, 0), tHi = min((px + rhoS) >> 4, 3);
+                    const int xm = tLo <= tHi ? (2 << tHi) - (1 << tLo) : 0; // bits tLo..tHi
+                    if (py + rhoS >= 0 && py - rhoS <= 15) tmask = xm;
+                    if (py + rhoS >= 16 && py - rhoS <= 31) tmask |= xm << 4;
+                }
+            }
+            // bit (4*ty + tx) of a quad's mask = some source of the quad reaches output tile (ty, tx): one MFMA
+            tmask |= __builtin_amdgcn_update_dpp(0, tmask, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+            tmask |= __builtin_amdgcn_update_dpp(0, tmask, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+            unsigned long long live = __ballot(tmask != 0);
+            const int qinfo = tmask | (sy << 8) | ((sx - cx0) << 20);   // one readlane per visit: mask, source row, column in window
+            if (!live) continue;                                     // no source of the chunk reaches the tile
+            // ---- build: weight table of one source per lane ----
             __builtin_amdgcn_wave_barrier();
             if (lane < CS) {
-                float rs = 0.0f;
-                int rhoS = -1;
-                if (dose != 0.0f) {
-                    rs = bevRSigmaEff[sliceOff + (size_t)sy * W + sx];
-                    const int own = tr[(sy >> 3) * fc.tilesX + (sx >> 5)];
-                    rhoS = own <= kMaxSuperpR ? eff[own] : -1;
-                    if (rhoS < 0) dose = 0.0f;
-                }
                 dArr[lane] = dose;
                 float* m = lds + lane * T;
-                float erfNew = 0.0f, erfOld = 0.0f;
-                if (rhoS >= 0) { erfNew = erff(rs * 0.5f); erfOld = -erfNew; }
                 float* mp = m + Tm;
                 float* mn = m + Tm;
-                for (int i = 0; i <= Tm; ++i) {
-                    float e = 0.0f;
-                    if (i <= rhoS) {
-                        e = 0.5f * (erfNew - erfOld);
-                        erfOld = erfNew;
-                        erfNew = erff(rs * ((float)i + 1.5f));
+                if (rhoS >= 0 && rs <= 0.5f) {
+                    // Pixel-integrated Gaussian weights e_i = (1/2)(erf(rs(i+1/2)) - erf(rs(i-1/2))) (kernel_wrapper.cuh:459-467)
+                    // evaluated as the Taylor series of the integral around the pixel centre x = rs*i:
+                    //   e_i = rs/sqrt(pi) * exp(-x^2) * (1 + H2(x) rs^2/24 + H4(x) rs^4/1920 + H6(x) rs^6/322560),
+                    //   H2 = 4x^2-2, H4 = 16x^4-48x^2+12, H6 = 64x^6-480x^4+720x^2-120  (g^(2n)/g of g = exp(-x^2)),
+                    // collected into a cubic in w = i^2 with per-source coefficients (3 FMAs per entry), and exp(-x^2)
+                    // advanced by the recurrence g_{i+1} = g_i q_i, q_{i+1} = q_i q_0^2, q_0 = exp(-rs^2).
+                    // For rs <= 0.5 (sigma >= 1.4 ray pixels) the truncation is < 3e-8 absolute — the size of the rounding of
+                    // the float erf DIFFERENCE itself (cancellation) — at ~10 vector instructions per entry instead of an erff
+                    // with its exp (~45). Sharper sources (few entries) keep the erff form below.
+                    const float h2 = rs * rs, h4 = h2 * h2;
+                    const float k1 = h2 * (1.0f / 24.0f), k2 = h4 * (1.0f / 1920.0f), k3 = h4 * h2 * (1.0f / 322560.0f);
+                    const float c0 = 1.0f - 2.0f * k1 + 12.0f * k2 - 120.0f * k3;
+                    const float c1 = (4.0f * k1 - 48.0f * k2 + 720.0f * k3) * h2;
+                    const float c2 = (16.0f * k2 - 480.0f * k3) * h4;
+                    const float c3 = 64.0f * k3 * (h4 * h2);
+                    float q = expf(-h2), gq = 0.5641895835f * rs;    // gq = rs/sqrt(pi) * exp(-x_i^2)
+                    const float cq = q * q;
+                    // two entries per trip (T = 2 Tm + 1 is odd: entry 0 first), so the LDS stores use immediate offsets
+                    const float e0 = c0 * gq;
+                    *mp = e0;
+                    gq *= q; q *= cq;
+                    for (int i = 1; i <= Tm; i += 2) {
+                        const float w0 = (float)(i * i), w1 = (float)((i + 1) * (i + 1));
+                        const float s0 = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(c3, w0, c2), w0, c1), w0, c0);
+                        const float s1 = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(c3, w1, c2), w1, c1), w1, c0);
+                        const float g1 = gq * q, q1 = q * cq;
+                        const float ea = i <= rhoS ? gq * s0 : 0.0f;
+                        const float eb = i + 1 <= rhoS ? g1 * s1 : 0.0f;
+                        gq = g1 * q1; q = q1 * cq;
+                        mp[i] = ea; mp[-i] = ea;
+                        if (i + 1 <= Tm) { mp[i + 1] = eb; mp[-i - 1] = eb; }
                     }
-                    *mp++ = e;
-                    *mn-- = e;
+                } else {
+                    float erfNew = 0.0f, erfOld = 0.0f;
+                    if (rhoS >= 0) { erfNew = erff(rs * 0.5f); erfOld = -erfNew; }
+                    for (int i = 0; i <= Tm; ++i) {
+                        float e = 0.0f;
+                        if (i <= rhoS) {
+                            e = 0.5f * (erfNew - erfOld);
+                            erfOld = erfNew;
+                            erfNew = erff(rs * ((float)i + 1.5f));
+                        }
+                        *mp++ = e;
+                        *mn-- = e;
+                    }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             // ---- accumulate: one MFMA per (source quad, 16x16 output tile) pair whose bands intersect ----
-            // Only quads that carry dose are visited: their lanes are taken from a wave ballot (scalar bit scan), the
-            // quad's grid position from the lane that built its first source.
-            unsigned long long live = __ballot(dose != 0.0f);
-            // Per-visit address arithmetic is done in LDS byte addresses: operand address = clamp(laneConst + visitScalar,
-            // table centre -4Tm, +4Tm) = one v_add + one v_med3 per operand (the clamp lands on the zero ends of the table
-            // when a tile is out of the source's reach).
-            const int ldsBase = (int)(size_t)(__attribute__((address_space(3))) float*)lds;   // LDS byte address of the slice
-            const int laneTab = ldsBase + (kq * T + Tm) * 4;         // + 16*q*T: centre of the lane's source table
-            const int laneA = laneTab + (oy0 + li - 32) * 4;         // + 64*t - 4*qRow
-            const int laneB = laneTab + (ox0 + li - kq - 32 - cx0) * 4;   // + 64*t - 4*qCol
-            const int laneD = ldsBase + (CS * T + kq) * 4;           // + 16*q: the lane's dose
+            // Only quads that reach the tile are visited: their lanes are taken from the wave ballot (scalar bit scan), mask
+            // and grid position from the lane that built the quad's first source (one readlane).
             while (live) {
                 const int q4 = __builtin_ctzll(live) & ~3;           // 4*q
                 live &= ~(0xFull << q4);
-                const int qRow = __builtin_amdgcn_readlane(sy, q4);
-                const int qCol = __builtin_amdgcn_readlane(sx, q4) - cx0;
+                const int qi = __builtin_amdgcn_readlane(qinfo, q4);
+                const int qm = qi & 0xFF, qRow4 = (qi >> 6) & 0x3FFC, qCol4 = (int)(((unsigned)qi >> 18) & 0x3FFC);
                 const int tabOff = q4 * T * 4;                       // scalar
                 const int ctr = laneTab + tabOff, lo = ctr - 4 * Tm, hi = ctr + 4 * Tm;
-                const int sa = tabOff - 4 * qRow, sb = tabOff - 4 * qCol;
-                int aA[2], aB[4];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) asm("v_med3_i32 %0, %1, %2, %3" : "=v"(aA[t]) : "v"(laneA + 64 * t + sa), "v"(lo), "v"(hi));
-#pragma unroll
-                for (int t = 0; t < 4; ++t) asm("v_med3_i32 %0, %1, %2, %3" : "=v"(aB[t]) : "v"(laneB + 64 * t + sb), "v"(lo), "v"(hi));
+                const int sa = tabOff - qRow4, sb = tabOff - qCol4;
                 typedef __attribute__((address_space(3))) const float* lptr;
                 const float dl = *(lptr)(size_t)(laneD + 4 * q4);
-                const float e0 = *(lptr)(size_t)aA[0], e1 = *(lptr)(size_t)aA[1];
-                const float bb[4] = { *(lptr)(size_t)aB[0], *(lptr)(size_t)aB[1], *(lptr)(size_t)aB[2], *(lptr)(size_t)aB[3] };
-                // wave-uniform tile ranges: tiles [tLo, tHi] intersect the quad's band in x, rows yb0 / yb1 in y
-                const int psy = qRow + 32, psx0 = cx0 + qCol + 32;   // padded coordinates of the quad's first source
-                const int tLo = max((psx0 - rho - ox0) >> 4, 0), tHi = min((psx0 + 3 + rho - ox0) >> 4, 3);
-                const bool ya0 = (oy0 <= psy + rho) && (oy0 + 15 >= psy - rho);
-                const bool ya1 = (oy0 + 16 <= psy + rho) && (oy0 + 31 >= psy - rho);
-                const float a0 = dl * e0, a1 = dl * e1;
+                // operands are fetched only for the tile rows / columns the quad reaches (qm): A = dose * m[row - y_s]
+                float a0, a1;                                        // each is read only under the mask bits that set it
+                if (qm & 0x0F) {
+                    int ad; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(ad) : "v"(laneA + sa), "v"(lo), "v"(hi));
+                    a0 = dl * *(lptr)(size_t)ad;
+                }
+                if (qm & 0xF0) {
+                    int ad; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(ad) : "v"(laneA + (sa + 64)), "v"(lo), "v"(hi));
+                    a1 = dl * *(lptr)(size_t)ad;
+                }
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    if (t >= tLo && t <= tHi) {
-                        if (ya0) acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bb[t], acc[0][t], 0, 0, 0);
-                        if (ya1) acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bb[t], acc[1][t], 0, 0, 0);
+                    if (qm & (0x11 << t)) {
+                        int ad; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(ad) : "v"(laneB + (sb + 64 * t)), "v"(lo), "v"(hi));
+                        const float bt = *(lptr)(size_t)ad;
+                        if (qm & (1 << t)) acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bt, acc[0][t], 0, 0, 0);
+                        if (qm & (16 << t)) acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bt, acc[1][t], 0, 0, 0);
                     }
                 }
             }
         }
+    }
+    // ---- the item's waves add their accumulators in fixed order (wave 0 + wave 1 + ...) through LDS ----
+    if (kKsSplit > 1) {
+        __syncthreads();                                             // every wave is done with its tables
+        for (int r = 1; r < kKsSplit; ++r) {
+            if (wv == r) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) ldsAll[((a * 4 + b) * 4 + c) * 64 + lane] = acc[a][b][c];
+            }
+            __syncthreads();
+            if (wv == 0) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) acc[a][b][c] += ldsAll[((a * 4 + b) * 4 + c) * 64 + lane];
+            }
+            if (r + 1 < kKsSplit) __syncthreads();
+        }
+        if (wv != 0) return;
     }
     // ---- epilogue: one plain store per partial element; D[row=(lane>>4)*4+reg][col=lane&15] ----
     float* out = bevPart + ((size_t)g * fc.S + k) * fc.bevW * fc.bevH;
