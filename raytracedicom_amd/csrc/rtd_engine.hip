@@ -34,6 +34,7 @@ struct rtd_handle_impl {
     hipStream_t stream = nullptr;
     std::string error;
     rtd_options opt{};
+    bool scanLdsSet = false;      // dynamic-LDS cap of k_trace_scan raised (once per handle)
     // LUTs
     bool haveLuts = false;
     std::vector<float> energiesPerU, peakDepths, scaleFacts;
@@ -460,7 +461,12 @@ int rtd_field_compute(rtd_handle hh, rtd_field ff, float* dev_dose) {
     // dIdd doubles as the HU scratch of the tracer (it is written by k_fill only afterwards)
     k_trace_sample<<<dim3((unsigned)(f->R / 256), (fc.S + kTraceSeg - 1) / kTraceSeg), 256, lutLds, s>>>(
         h->dCt, (int)h->ctDims[0], (int)h->ctDims[1], (int)h->ctDims[2], h->lut, f->tracer, fc.W, fc.H, f->dDensity, f->dWepl, f->dIdd);
-    k_trace_scan<<<(unsigned)(f->R / 64), 64, 0, s>>>(f->dIdd, f->dWepl, fc.W, fc.H, (unsigned)fc.S, f->dFirstInside, f->dFirstOutside,
+    constexpr size_t scanLds = 2 * kScanChunk * 64 * sizeof(float);   // 128 KiB: above the 64 KiB default cap of dynamic LDS
+    if (!h->scanLdsSet) {
+        RTD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_trace_scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scanLds));
+        h->scanLdsSet = true;
+    }
+    k_trace_scan<<<(unsigned)(f->R / 64), dim3(64, kScanWaves), scanLds, s>>>(f->dIdd, f->dWepl, fc.W, fc.H, (unsigned)fc.S, f->dFirstInside, f->dFirstOutside,
                                                      f->dState);
     k_slice_min<<<fc.S, 256, 0, s>>>(f->dWepl, f->R, f->dWeplMin);
     if (timing) RTD_HIP(h, hipEventRecord(f->ev[1], s));

@@ -14,6 +14,8 @@
 namespace rtd {
 
 constexpr int kWave = 64;
+constexpr int kKsTileX = 64, kKsTileY = 32;   // superposition: output tile owned by one wave (4 x 2 MFMA tiles)
+constexpr int kKsMaxOrder = 64;               // superposition: output tiles ranked by expected work when there are at most this many
 constexpr int kMaxLayers = 256;
 constexpr int kMaxSteps = 4096;
 constexpr int kNoRadius = 0xFF;
@@ -55,6 +57,7 @@ struct FieldState {
     int groupPassive[32];           // per superposition layer group: first step at which none of its layers deposits
     int actUnion[4];                // minima of (x, y, -x, -y) over all rays that carry dose in any (layer, step)
     int bevLo[2], bevHi[2];         // padded-BEV rectangle outside which every slice is exactly zero (transfer early-out)
+    unsigned char tileOrder[kKsMaxOrder];   // superposition dispatch order of the output tiles: most source rays in reach first
 };
 
 // Host-known per-field constants, passed by value.
@@ -163,11 +166,11 @@ __global__ void k_reset(FieldState* st, LayerPlan* layers, int L) {
 //   k_trace_sample  one thread per (ray, segment of kTraceSeg steps): trilinear HU sample, density LUT, and the
 //                   step's stopping-power term stepLen*SP(hu). The sample position is advanced with the
 //                   reference's repeated `pos += step` (arithmetic only) so it is the same float sequence.
-//   k_trace_scan    one thread per ray: the reference's sequential sums (cumulSp, cumulHuPlus1000) and entry/exit
+//   k_trace_scan    three waves per 64 rays: the reference's sequential sums (cumulSp, cumulHuPlus1000) and entry/exit
 //                   logic over the stored terms, fused with the int reductions that follow the tracer in the
 //                   reference (sliceMin/MaxVar<int>, kernel_wrapper.cu:781-787).
 // Rays are numbered row-major; lanes hold consecutive rays, so all stores are coalesced and step-major.
-constexpr int kTraceSeg = 32;
+constexpr int kTraceSeg = 8;
 
 __global__ __launch_bounds__(256) void k_trace_sample(const float* __restrict__ ct, int nx, int ny, int nz, LutView lut,
                                                        TracerParams tp, int W, int H, float* __restrict__ bevDensity,
@@ -176,20 +179,29 @@ __global__ __launch_bounds__(256) void k_trace_sample(const float* __restrict__ 
     float* sDensity = sLut;
     float* sSp = sLut + lut.nDensity;
     const int tid = threadIdx.x;
-    for (int i = tid; i < lut.nDensity; i += 256) sDensity[i] = lut.density[i];
-    for (int i = tid; i < lut.nSp; i += 256) sSp[i] = lut.sp[i];
-    __syncthreads();
-
     const int ray = blockIdx.x * 256 + tid;
     const int x = ray % W, y = ray / W;
     const size_t memStep = (size_t)W * H;
     const unsigned int k0 = blockIdx.y * kTraceSeg;
     const unsigned int k1 = min(k0 + kTraceSeg, tp.steps);
 
+    // the LUT rows travel to LDS while the start position of the segment is being accumulated
+    constexpr int kLutRegs = 16;                                     // covers 2 x 2048 entries in registers; longer tables loop
+    float rl[kLutRegs];
+    const int nLut = lut.nDensity + lut.nSp;
+#pragma unroll
+    for (int j = 0; j < kLutRegs; ++j) {
+        const int i = tid + 256 * j;
+        rl[j] = i < lut.nDensity ? lut.density[i] : (i < nLut ? lut.sp[i - lut.nDensity] : 0.0f);
+    }
     Vec3 pos = tp.getStart(x, y);     // texel-centre +0.5 of kernel_wrapper.cu:142 is implicit in the sampler
     const Vec3 step = tp.getInc(x, y);
     const float stepLen = tp.stepLen(x, y);
     for (unsigned int i = 0; i < k0; ++i) pos = pos + step;          // same float sequence as the serial walk (:183)
+#pragma unroll
+    for (int j = 0; j < kLutRegs; ++j) { const int i = tid + 256 * j; if (i < nLut) sLut[i] = rl[j]; }
+    for (int i = tid + 256 * kLutRegs; i < nLut; i += 256) sLut[i] = i < lut.nDensity ? lut.density[i] : lut.sp[i - lut.nDensity];
+    __syncthreads();
     size_t idx = (size_t)k0 * memStep + ray;
     for (unsigned int i = k0; i < k1; ++i) {
         const float huPlus1000 = sample3dBorder(ct, nx, ny, nz, pos.x, pos.y, pos.z);
@@ -201,43 +213,95 @@ __global__ __launch_bounds__(256) void k_trace_sample(const float* __restrict__ 
     }
 }
 
-__global__ __launch_bounds__(64) void k_trace_scan(const float* __restrict__ huBuf, float* __restrict__ bevCumulSp, int W, int H,
-                                                    unsigned int steps, int* __restrict__ firstInside, int* __restrict__ firstOutside,
-                                                    FieldState* st) {
-    const int ray = blockIdx.x * 64 + threadIdx.x;
+// The sums are serial per ray (float order of the reference walk, kernel_wrapper.cu:147-186), so only R/64 serial
+// chains of 64 lanes exist: a plain one-wave-per-64-rays walk keeps ~2 MB of loads in flight and is bound by memory
+// latency (measured 57 us for 51 MB). Here a block of kScanWaves waves serves 64 rays: ALL waves stream the next chunk of
+// kScanChunk steps (hu and stepLen*SP terms) into registers and then LDS, while three of them walk the current chunk
+// out of LDS, one serial chain each:
+//   wave 0: cumulSp (WEPL; written back into the chunk, then stored by all waves)
+//   wave 1: cumulHu -> beforeFirstInside (:173-176)        wave 2: hu > 150 -> lastInside (:177-180)
+constexpr int kScanWaves = 16, kScanChunk = 256, kScanPerWave = kScanChunk / kScanWaves;
+__global__ __launch_bounds__(64 * kScanWaves) void k_trace_scan(const float* __restrict__ huBuf, float* __restrict__ bevCumulSp, int W, int H,
+                                                                 unsigned int steps, int* __restrict__ firstInside, int* __restrict__ firstOutside,
+                                                                 FieldState* st) {
+    extern __shared__ float sScan[];                                 // [hu, sp][kScanChunk][64]; the next chunk waits in registers
+    const int lane = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int ray = blockIdx.x * 64 + lane;
     const size_t memStep = (size_t)W * H;
-    size_t idx = ray;
+    auto sHu = [&](int, int i) -> float& { return sScan[i * 64 + lane]; };
+    auto sSp = [&](int, int i) -> float& { return sScan[(kScanChunk + i) * 64 + lane]; };
+    float rHu[kScanPerWave], rSp[kScanPerWave];
+    auto fetch = [&](unsigned int c0) {                              // this wave's kScanPerWave steps of the chunk starting at c0
+#pragma unroll
+        for (int j = 0; j < kScanPerWave; ++j) {
+            const unsigned int i = c0 + wv * kScanPerWave + j;
+            rHu[j] = i < steps ? huBuf[ray + (size_t)i * memStep] : 0.0f;
+            rSp[j] = i < steps ? bevCumulSp[ray + (size_t)i * memStep] : 0.0f;   // holds stepLen*SP(hu) from k_trace_sample
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < kScanPerWave; ++j) { sHu(buf, wv * kScanPerWave + j) = rHu[j]; sSp(buf, wv * kScanPerWave + j) = rSp[j]; }
+    };
     float cumulSp = 0.0f, cumulHuPlus1000 = 0.0f;
     int beforeFirstInside = -1, lastInside = -1;
-    // batches of kScanBatch steps: all loads of a batch are issued before the serial sums consume them, so the
-    // walk is bound by arithmetic, not by one memory round trip per step
-    constexpr int kScanBatch = 16;
-    for (unsigned int i0 = 0; i0 < steps; i0 += kScanBatch) {
-        float hu[kScanBatch], sp[kScanBatch];
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    int buf = 0;
+    for (unsigned int c0 = 0; c0 < steps; c0 += kScanChunk, buf ^= 1) {
+        if (c0 + kScanChunk < steps) fetch(c0 + kScanChunk);         // in flight during the walks below
+        // (steps past the end were staged as zeros: they change no sum and set no index)
+        constexpr int kU = 16;                                       // LDS reads issued ahead of the serial adds
+        if (wv == 0) {
+            for (int j0 = 0; j0 < kScanChunk; j0 += kU) {
+                float v[kU];
 #pragma unroll
-        for (int j = 0; j < kScanBatch; ++j) {
-            const bool in = i0 + j < steps;
-            hu[j] = in ? huBuf[idx + (size_t)j * memStep] : 0.0f;
-            sp[j] = in ? bevCumulSp[idx + (size_t)j * memStep] : 0.0f;   // holds stepLen*SP(hu) from k_trace_sample
-        }
+                for (int j = 0; j < kU; ++j) v[j] = sSp(buf, j0 + j);
 #pragma unroll
-        for (int j = 0; j < kScanBatch; ++j) {
-            const unsigned int i = i0 + j;
-            if (i < steps) {
-                const float huPlus1000 = hu[j];
-                cumulHuPlus1000 += huPlus1000;
-                cumulSp += sp[j];
-                if (cumulHuPlus1000 < 150.0f) beforeFirstInside = (int)i;
-                if (huPlus1000 > 150.0f) lastInside = (int)i;
-                bevCumulSp[idx + (size_t)j * memStep] = cumulSp;
+                for (int j = 0; j < kU; ++j) { cumulSp += v[j]; sSp(buf, j0 + j) = cumulSp; }
+            }
+        } else if (wv == 1) {
+            for (int j0 = 0; j0 < kScanChunk; j0 += kU) {
+                float v[kU];
+#pragma unroll
+                for (int j = 0; j < kU; ++j) v[j] = sHu(buf, j0 + j);
+#pragma unroll
+                for (int j = 0; j < kU; ++j) {
+                    cumulHuPlus1000 += v[j];
+                    if (cumulHuPlus1000 < 150.0f && c0 + j0 + j < steps) beforeFirstInside = (int)(c0 + j0 + j);
+                }
+            }
+        } else if (wv == 2) {
+            for (int j0 = 0; j0 < kScanChunk; j0 += kU) {
+                float v[kU];
+#pragma unroll
+                for (int j = 0; j < kU; ++j) v[j] = sHu(buf, j0 + j);
+#pragma unroll
+                for (int j = 0; j < kU; ++j) if (v[j] > 150.0f) lastInside = (int)(c0 + j0 + j);
             }
         }
-        idx += (size_t)kScanBatch * memStep;
+        __syncthreads();                                             // chunk walked
+#pragma unroll
+        for (int j = 0; j < kScanPerWave; ++j) {                     // all waves store the chunk's WEPL
+            const unsigned int i = c0 + wv * kScanPerWave + j;
+            if (i < steps) bevCumulSp[ray + (size_t)i * memStep] = sSp(buf, wv * kScanPerWave + j);
+        }
+        if (c0 + kScanChunk < steps) {
+            __syncthreads();                                         // chunk stored: the buffer takes the next one
+            stage(buf);
+            __syncthreads();
+        }
     }
-    firstInside[ray] = beforeFirstInside + 1;
-    firstOutside[ray] = lastInside + 1;
-    int mn = waveMinI(beforeFirstInside + 1), mx = waveMaxI(lastInside + 1);
-    if (threadIdx.x == 0) { atomicMin(&st->beamFirstInside, mn); atomicMax(&st->beamFirstOutside, mx); }
+    if (wv == 1) {
+        firstInside[ray] = beforeFirstInside + 1;
+        const int mn = waveMinI(beforeFirstInside + 1);
+        if (lane == 0) atomicMin(&st->beamFirstInside, mn);
+    } else if (wv == 2) {
+        firstOutside[ray] = lastInside + 1;
+        const int mx = waveMaxI(lastInside + 1);
+        if (lane == 0) atomicMax(&st->beamFirstOutside, mx);
+    }
 }
 
 // sliceMinVar<float> (kernel_wrapper.cuh:215-244, launch kernel_wrapper.cu:788): smallest WEPL of every step.
@@ -540,25 +604,56 @@ __global__ void k_ks_plan(FieldState* st, LayerPlan* layers, FieldConst fc, From
     const int first = st->beamFirstInside;
     for (int l = threadIdx.x; l < fc.L; l += blockDim.x) {
         LayerPlan& p = layers[l];
+        int hist[kMaxSuperpR + 2], effRad[kMaxSuperpR + 2];          // one round trip for the histogram, one for the result
+#pragma unroll
+        for (int i = 0; i < kMaxSuperpR + 2; ++i) hist[i] = p.hist[i];
         int layerMax = 0;
-        for (int i = 0; i < kMaxSuperpR + 2; ++i) if (p.hist[i] > 0) layerMax = i;
+#pragma unroll
+        for (int i = 0; i < kMaxSuperpR + 2; ++i) { if (hist[i] > 0) layerMax = i; effRad[i] = i; }
         // tiles at steps >= layerFirstPassive are not classified by the reference; they can only be radius 0
-        if (p.hist[kMaxSuperpR + 1] > 0) atomicOr(&st->errorFlags, kErrRadiusOverflow);
-        for (int i = 0; i < kMaxSuperpR + 2; ++i) p.effRad[i] = i;
+        if (hist[kMaxSuperpR + 1] > 0) atomicOr(&st->errorFlags, kErrRadiusOverflow);
         if (layerMax <= kMaxSuperpR) {
             int rec = layerMax, batched = 0;
-            for (int rad = layerMax; rad > 0; --rad) {
-                batched += p.hist[rad];
-                p.effRad[rad] = rec;
-                if (batched >= kMinTilesInBatch) { rec = rad - 1; batched = 0; }
+#pragma unroll
+            for (int rad = kMaxSuperpR; rad > 0; --rad) {
+                if (rad <= layerMax) {
+                    batched += hist[rad];
+                    effRad[rad] = rec;
+                    if (batched >= kMinTilesInBatch) { rec = rad - 1; batched = 0; }
+                }
             }
         }
+#pragma unroll
+        for (int i = 0; i < kMaxSuperpR + 2; ++i) p.effRad[i] = effRad[i];
         atomicMax(&sMaxRad, layerMax);
         atomicMax(&sMaxPassive, p.layerFirstPassive);
         atomicMax(&sGroup[l % G], p.layerFirstPassive);
         if (p.layerFirstPassive > first) atomicAdd(&sLive, (unsigned long long)(p.layerFirstPassive - first));
     }
     __syncthreads();
+    {   // Output tiles of the superposition ranked by the number of dose-carrying rays within reach: the work items of the
+        // busiest tiles are dispatched first, the items of margin tiles (short) last, so the kernel does not end on a few
+        // long items. One tile per thread, stable rank by counting.
+        __shared__ int sArea[kKsMaxOrder];
+        const int nTX = (fc.bevW + kKsTileX - 1) / kKsTileX, nTY = (fc.bevH + kKsTileY - 1) / kKsTileY, n = nTX * nTY;
+        if (n <= kKsMaxOrder) {                                      // blockDim.x == 64 == kKsMaxOrder
+            const int rr = min(sMaxRad, kMaxSuperpR), t = threadIdx.x;
+            int area = 0;
+            if (t < n) {
+                const int ox0 = (t % nTX) * kKsTileX, oy0 = (t / nTX) * kKsTileY;
+                const int w = min(ox0 + 31 + rr, -st->actUnion[2]) - max(ox0 - 32 - rr, st->actUnion[0]) + 1;
+                const int h = min(oy0 - 1 + rr, -st->actUnion[3]) - max(oy0 - 32 - rr, st->actUnion[1]) + 1;
+                area = (w > 0 && h > 0) ? w * h : 0;
+                sArea[t] = area;
+            }
+            __syncthreads();
+            if (t < n) {
+                int rank = 0;
+                for (int u = 0; u < n; ++u) { const int au = sArea[u]; rank += (au > area || (au == area && u < t)) ? 1 : 0; }
+                st->tileOrder[rank] = (unsigned char)t;
+            }
+        }
+    }
     if (threadIdx.x == 0) {
         const int calcPassive = sMaxPassive;
         st->firstCalculatedPassive = calcPassive;
@@ -610,7 +705,6 @@ __global__ void k_ks_plan(FieldState* st, LayerPlan* layers, FieldConst fc, From
 // flush, kernel_wrapper.cuh:486), no zero-fill pass (kernel_wrapper.cu:824-827): each partial element is stored
 // once and k_superpose_reduce adds the G partials in fixed order, so the BEV dose is bitwise reproducible.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int kKsTileX = 64, kKsTileY = 32;   // output tile owned by one wave (4 x 2 MFMA tiles)
 constexpr int kKsSplit = 1;                   // waves per work item (its source chunks are dealt round-robin to them, accumulators
                                               // summed through LDS at the end); measured: 2 = no gain, 4 = slower, so 1 (single-wave blocks)
 constexpr int kKsWaveLds = 1200;              // floats of LDS per wave (4.7 KiB): tables [CS][T] + doses [CS]; with the reach table
@@ -632,12 +726,12 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
     int* effT = reinterpret_cast<int*>(lds + kKsWaveLds);          // batch radius of every source tile in reach (-1: none)
     const int lane = threadIdx.x & 63;
     // One wave per block: a heavy item never keeps three finished neighbours' LDS and wave slots occupied.
-    // decode the work item (wave-uniform): fastest index = tile x, then tile y, then group, then step
+    // decode the work item (wave-uniform): fastest index = layer group, then step, then output tile
     int item = blockIdx.x;
-    const int tX = item % nTX; item /= nTX;
-    const int tY = item % nTY; item /= nTY;
-    const int g = item % G;
-    const int k = fc.S - 1 - item / G;                                // deepest steps (largest radii, most work) are dispatched first
+    const int g = item % G; item /= G;
+    const int k = fc.S - 1 - item % fc.S; item /= fc.S;               // within a tile the deepest steps (largest radii) go first
+    const int tile = nTX * nTY <= kKsMaxOrder ? st->tileOrder[item] : item;   // busiest tiles first (k_ks_plan)
+    const int tX = tile % nTX, tY = tile / nTX;
     const int first = st->beamFirstInside, calcPassive = st->firstCalculatedPassive;
     if (k < 0 || k < first || k >= calcPassive) return;
     if (k >= st->groupPassive[g]) return;                             // no layer of this group deposits at k: the reduce skips this partial
