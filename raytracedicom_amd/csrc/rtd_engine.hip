@@ -8,6 +8,7 @@
 //     to the host between kernels (:783,787,790,954,963) stays in device memory (k_plan, k_ks_plan).
 // There is no CPU fallback: without a HIP device every entry point fails with RTD_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdio>
@@ -65,7 +66,7 @@ struct rtd_field_impl {
     int* dActive = nullptr;      // [L][S][4] minima of (x, y, -x, -y) over rays with dose > 0
     FieldState* dState = nullptr;
     std::vector<LayerPlan> hLayers;
-    hipEvent_t ev[8] = {};
+    hipEvent_t ev[9] = {};       // 0..6 stage ends, 7 / 8 stop / start of k_superpose_mfma
     bool computed = false;
     int ksGroups = 20;   // layer groups of the superposition (partial BEV buffers); RTD_KS_GROUPS overrides
 };
@@ -455,8 +456,10 @@ int rtd_field_compute(rtd_handle hh, rtd_field ff, float* dev_dose) {
     const dim3 blk(kSuperpTileX, kSuperpTileY);
     const dim3 rayGrid(fc.W / kSuperpTileX, fc.H / kSuperpTileY);
 
-    RTD_HIP(h, hipEventRecord(f->ev[0], s));
-    k_reset<<<1, 256, 0, s>>>(f->dState, f->dLayers, fc.L);
+    // Stage boundaries are the start / stop timestamps of the kernels themselves (hipExtLaunchKernelGGL), not event
+    // packets between them: no barrier packet and no idle gap is inserted into the stream by the timing.
+    auto ev = [&](int i) -> hipEvent_t { return timing ? f->ev[i] : nullptr; };
+    hipExtLaunchKernelGGL(k_reset, dim3(1), dim3(256), 0, s, f->ev[0], nullptr, 0, f->dState, f->dLayers, fc.L);
     const size_t lutLds = (size_t)(h->lut.nDensity + h->lut.nSp) * sizeof(float);
     // dIdd doubles as the HU scratch of the tracer (it is written by k_fill only afterwards)
     k_trace_sample<<<dim3((unsigned)(f->R / 256), (fc.S + kTraceSeg - 1) / kTraceSeg), 256, lutLds, s>>>(
@@ -468,41 +471,41 @@ int rtd_field_compute(rtd_handle hh, rtd_field ff, float* dev_dose) {
     }
     k_trace_scan<<<(unsigned)(f->R / 64), dim3(64, kScanWaves), scanLds, s>>>(f->dIdd, f->dWepl, fc.W, fc.H, (unsigned)fc.S, f->dFirstInside, f->dFirstOutside,
                                                      f->dState);
-    k_slice_min<<<fc.S, 256, 0, s>>>(f->dWepl, f->R, f->dWeplMin);
-    if (timing) RTD_HIP(h, hipEventRecord(f->ev[1], s));
+    hipExtLaunchKernelGGL(k_slice_min, dim3(fc.S), dim3(256), 0, s, nullptr, ev(1), 0, (const float*)f->dWepl, (size_t)f->R, f->dWeplMin);
     k_plan<<<1, 64, 0, s>>>(f->dState, f->dLayers, f->dWeplMin, fc);
     RTD_HIP(h, hipMemsetAsync(f->dTileRad, kNoRadius, (size_t)fc.L * fc.S * fc.tilesX * fc.tilesY, s));
     RTD_HIP(h, hipMemsetAsync(f->dActive, 0x7f, (size_t)4 * fc.L * fc.S * sizeof(int), s));   // +large: empty rectangles
     k_conv_x<<<dim3(fc.W / 32, (fc.spotNy + 7) / 8, fc.L), blk, 0, s>>>(f->dSpotWeights, f->dConvInterm, f->dLayers, f->dState, fc);
-    k_conv_y<<<dim3(fc.W / 32, fc.H / 8, fc.L), blk, 0, s>>>(f->dConvInterm, f->dRayWeights, f->dLayers, f->dState, fc);
-    if (timing) RTD_HIP(h, hipEventRecord(f->ev[2], s));
+    hipExtLaunchKernelGGL(k_conv_y, dim3(fc.W / 32, fc.H / 8, fc.L), blk, 0, s, nullptr, ev(2), 0, (const float*)f->dConvInterm, f->dRayWeights,
+                          (const LayerPlan*)f->dLayers, (const FieldState*)f->dState, fc);
     {
         const size_t fillLds = (size_t)(2 * h->lut.nSamples + h->lut.nRrl) * sizeof(float);
         const dim3 fillGrid(rayGrid.x, rayGrid.y, fc.L);
         if (fillLds <= 96 * 1024)
-            k_fill<true><<<fillGrid, blk, fillLds, s>>>(f->dDensity, f->dWepl, f->dIdd, f->dRSigma, f->dRayWeights, f->dFirstInside, f->dFirstOutside,
-                                                        f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc, f->dStepTab, f->dActive);
+            hipExtLaunchKernelGGL((k_fill<true>), fillGrid, blk, fillLds, s, nullptr, ev(3), 0, (const float*)f->dDensity, (const float*)f->dWepl, f->dIdd,
+                                  f->dRSigma, (const float*)f->dRayWeights, (const int*)f->dFirstInside, (const int*)f->dFirstOutside,
+                                  f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc, (const float*)f->dStepTab, f->dActive);
         else
-            k_fill<false><<<fillGrid, blk, 0, s>>>(f->dDensity, f->dWepl, f->dIdd, f->dRSigma, f->dRayWeights, f->dFirstInside, f->dFirstOutside,
-                                                   f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc, f->dStepTab, f->dActive);
+            hipExtLaunchKernelGGL((k_fill<false>), fillGrid, blk, 0, s, nullptr, ev(3), 0, (const float*)f->dDensity, (const float*)f->dWepl, f->dIdd,
+                                  f->dRSigma, (const float*)f->dRayWeights, (const int*)f->dFirstInside, (const int*)f->dFirstOutside,
+                                  f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc, (const float*)f->dStepTab, f->dActive);
     }
-    if (timing) RTD_HIP(h, hipEventRecord(f->ev[3], s));
-    k_ks_plan<<<1, 64, 0, s>>>(f->dState, f->dLayers, fc, f->rayIdxToDoseIdx, f->transfer0, (int)f->doseDims[0], (int)f->doseDims[1],
-                               (int)f->doseDims[2], f->ksGroups);
-    if (timing) RTD_HIP(h, hipEventRecord(f->ev[4], s));
+    hipExtLaunchKernelGGL(k_ks_plan, dim3(1), dim3(64), 0, s, nullptr, ev(4), 0, f->dState, f->dLayers, fc, f->rayIdxToDoseIdx, f->transfer0,
+                          (int)f->doseDims[0], (int)f->doseDims[1], (int)f->doseDims[2], f->ksGroups);
     {
         const int nTX = (fc.bevW + kKsTileX - 1) / kKsTileX, nTY = (fc.bevH + kKsTileY - 1) / kKsTileY;
         const int G = f->ksGroups;
         const int nItems = fc.S * G * nTY * nTX;
-        k_superpose_mfma<<<nItems, 64 * kKsSplit, 0, s>>>(f->dIdd, f->dRSigma, f->dBevPart, f->dTileRad, f->dLayers, f->dState, fc, nTX, nTY, G, f->dActive);
-        if (timing) RTD_HIP(h, hipEventRecord(f->ev[7], s));
-        k_superpose_reduce<<<1024, 256, 0, s>>>(f->dBevPart, f->dBev, f->dState, fc, G);
+        hipExtLaunchKernelGGL(k_superpose_mfma, dim3(nItems), dim3(64 * kKsSplit), 0, s, ev(8), ev(7), 0, (const float*)f->dIdd, (const float*)f->dRSigma,
+                              f->dBevPart, (const unsigned char*)f->dTileRad, (const LayerPlan*)f->dLayers, (const FieldState*)f->dState, fc, nTX, nTY, G,
+                              (const int*)f->dActive);
+        hipExtLaunchKernelGGL(k_superpose_reduce, dim3(1024), dim3(256), 0, s, nullptr, ev(5), 0, (const float*)f->dBevPart, f->dBev,
+                              (const FieldState*)f->dState, fc, G);
     }
-    if (timing) RTD_HIP(h, hipEventRecord(f->ev[5], s));
     const int zChunk = 16;
-    k_transfer<<<dim3((f->doseDims[0] + 31) / 32, (f->doseDims[1] + 7) / 8, (f->doseDims[2] + zChunk - 1) / zChunk), blk, 0, s>>>(
-        dev_dose, (int)f->doseDims[0], (int)f->doseDims[1], (int)f->doseDims[2], f->dBev, f->dState, fc, zChunk);
-    RTD_HIP(h, hipEventRecord(f->ev[6], s));
+    hipExtLaunchKernelGGL(k_transfer, dim3((f->doseDims[0] + 31) / 32, (f->doseDims[1] + 7) / 8, (f->doseDims[2] + zChunk - 1) / zChunk), blk, 0, s,
+                          nullptr, f->ev[6], 0, dev_dose, (int)f->doseDims[0], (int)f->doseDims[1], (int)f->doseDims[2], (const float*)f->dBev,
+                          (const FieldState*)f->dState, fc, zChunk);
     RTD_HIP(h, hipGetLastError());
     f->computed = true;
     return RTD_OK;
@@ -525,7 +528,7 @@ int rtd_field_finish(rtd_handle hh, rtd_field ff, rtd_timing* timing, rtd_field_
             RTD_HIP(h, hipEventElapsedTime(&timing->fill_idd_sigma_ms, f->ev[2], f->ev[3]));
             RTD_HIP(h, hipEventElapsedTime(&timing->prepare_superp_ms, f->ev[3], f->ev[4]));
             RTD_HIP(h, hipEventElapsedTime(&timing->superp_ms, f->ev[4], f->ev[5]));
-            RTD_HIP(h, hipEventElapsedTime(&timing->superp_kernel_ms, f->ev[4], f->ev[7]));
+            RTD_HIP(h, hipEventElapsedTime(&timing->superp_kernel_ms, f->ev[8], f->ev[7]));
             RTD_HIP(h, hipEventElapsedTime(&timing->transforming_ms, f->ev[5], f->ev[6]));
         }
         timing->superp_launches = 2;   // k_superpose_mfma + k_superpose_reduce (the reference: up to 33 per layer)
