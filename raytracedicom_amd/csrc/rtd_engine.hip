@@ -35,6 +35,7 @@ struct rtd_handle_impl {
     hipStream_t stream = nullptr;
     std::string error;
     rtd_options opt{};
+    int numCUs = 256;             // compute units of the device (grid size of the grid-stride kernels)
     bool scanLdsSet = false;      // dynamic-LDS cap of k_trace_scan raised (once per handle)
     // LUTs
     bool haveLuts = false;
@@ -144,6 +145,7 @@ int rtd_create(int device_id, rtd_handle* out) {
         return RTD_ERR_HIP;
     }
     h->stream = h->ownStream;
+    if (hipDeviceGetAttribute(&h->numCUs, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || h->numCUs <= 0) h->numCUs = 256;
     *out = reinterpret_cast<rtd_handle>(h);
     return RTD_OK;
 }
@@ -503,9 +505,13 @@ int rtd_field_compute(rtd_handle hh, rtd_field ff, float* dev_dose) {
                               (const FieldState*)f->dState, fc, G);
     }
     const int zChunk = 16;
-    hipExtLaunchKernelGGL(k_transfer, dim3((f->doseDims[0] + 31) / 32, (f->doseDims[1] + 7) / 8, (f->doseDims[2] + zChunk - 1) / zChunk), blk, 0, s,
-                          nullptr, f->ev[6], 0, dev_dose, (int)f->doseDims[0], (int)f->doseDims[1], (int)f->doseDims[2], (const float*)f->dBev,
-                          (const FieldState*)f->dState, fc, zChunk);
+    {
+        // grid-stride over the bricks of the device-side box; never more blocks than bricks of the whole volume
+        const size_t allBricks = (size_t)((f->doseDims[0] + 31) / 32) * ((f->doseDims[1] + 7) / 8) * ((f->doseDims[2] + zChunk - 1) / zChunk);
+        const unsigned tg = (unsigned)std::min<size_t>(allBricks, (size_t)h->numCUs * 8 * 4);
+        hipExtLaunchKernelGGL(k_transfer, dim3(tg), blk, 0, s, nullptr, f->ev[6], 0, dev_dose, (int)f->doseDims[0], (int)f->doseDims[1],
+                              (int)f->doseDims[2], (const float*)f->dBev, (const FieldState*)f->dState, fc, zChunk);
+    }
     RTD_HIP(h, hipGetLastError());
     f->computed = true;
     return RTD_OK;

@@ -52,6 +52,7 @@ struct FieldState {
     int maxRadius;
     long long liveSteps;
     int bboxMin[3], bboxMax[3];     // :1207-1208
+    int tboxMin[3], tboxMax[3];     // sub-box of it that can receive dose: image of the non-zero BEV rectangle (transfer loops over this)
     TransferParams transfer;        // :1213
     int empty;                      // nothing inside the patient for this beam
     int groupPassive[32];           // per superposition layer group: first step at which none of its layers deposits
@@ -133,10 +134,23 @@ __device__ inline float sample3dBorder(const float* __restrict__ vol, int nx, in
     float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
     float ax = px - fx, ay = py - fy, az = pz - fz;
     int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
-    float c00 = lerpW(ax, fetch3dBorder(vol, nx, ny, nz, x0, y0, z0), fetch3dBorder(vol, nx, ny, nz, x0 + 1, y0, z0));
-    float c10 = lerpW(ax, fetch3dBorder(vol, nx, ny, nz, x0, y0 + 1, z0), fetch3dBorder(vol, nx, ny, nz, x0 + 1, y0 + 1, z0));
-    float c01 = lerpW(ax, fetch3dBorder(vol, nx, ny, nz, x0, y0, z0 + 1), fetch3dBorder(vol, nx, ny, nz, x0 + 1, y0, z0 + 1));
-    float c11 = lerpW(ax, fetch3dBorder(vol, nx, ny, nz, x0, y0 + 1, z0 + 1), fetch3dBorder(vol, nx, ny, nz, x0 + 1, y0 + 1, z0 + 1));
+    float v000, v100, v010, v110, v001, v101, v011, v111;
+    if (x0 >= 0 && y0 >= 0 && z0 >= 0 && x0 + 1 < nx && y0 + 1 < ny && z0 + 1 < nz) {
+        // interior cell (almost every sample): one index, eight plain loads, no per-corner bounds logic
+        const float* p = vol + ((size_t)(unsigned)(z0 * ny + y0) * (unsigned)nx + (unsigned)x0);
+        const size_t sxy = (size_t)(unsigned)nx * (unsigned)ny;
+        v000 = p[0]; v100 = p[1]; v010 = p[nx]; v110 = p[nx + 1];
+        v001 = p[sxy]; v101 = p[sxy + 1]; v011 = p[sxy + nx]; v111 = p[sxy + nx + 1];
+    } else {
+        v000 = fetch3dBorder(vol, nx, ny, nz, x0, y0, z0);         v100 = fetch3dBorder(vol, nx, ny, nz, x0 + 1, y0, z0);
+        v010 = fetch3dBorder(vol, nx, ny, nz, x0, y0 + 1, z0);     v110 = fetch3dBorder(vol, nx, ny, nz, x0 + 1, y0 + 1, z0);
+        v001 = fetch3dBorder(vol, nx, ny, nz, x0, y0, z0 + 1);     v101 = fetch3dBorder(vol, nx, ny, nz, x0 + 1, y0, z0 + 1);
+        v011 = fetch3dBorder(vol, nx, ny, nz, x0, y0 + 1, z0 + 1); v111 = fetch3dBorder(vol, nx, ny, nz, x0 + 1, y0 + 1, z0 + 1);
+    }
+    float c00 = lerpW(ax, v000, v100);
+    float c10 = lerpW(ax, v010, v110);
+    float c01 = lerpW(ax, v001, v101);
+    float c11 = lerpW(ax, v011, v111);
     float c0 = lerpW(ay, c00, c10);
     float c1 = lerpW(ay, c01, c11);
     return lerpW(az, c0, c1);
@@ -151,7 +165,7 @@ __global__ void k_reset(FieldState* st, LayerPlan* layers, int L) {
         st->firstCalculatedPassive = 0; st->errorFlags = 0; st->maxRadius = 0; st->liveSteps = 0;
         st->empty = 0;
         for (int i = 0; i < 4; ++i) st->actUnion[i] = 0x7fffffff;
-        for (int i = 0; i < 3; ++i) { st->bboxMin[i] = 0; st->bboxMax[i] = 0; }
+        for (int i = 0; i < 3; ++i) { st->bboxMin[i] = 0; st->bboxMax[i] = 0; st->tboxMin[i] = 0; st->tboxMax[i] = -1; }
     }
     for (int l = t; l < L; l += gridDim.x * blockDim.x) {
         layers[l].layerFirstPassive = 0; layers[l].afterLast = 0;
@@ -684,6 +698,23 @@ __global__ void k_ks_plan(FieldState* st, LayerPlan* layers, FieldConst fc, From
             t = (int)ceilf(maxP.x); st->bboxMax[0] = t < doseNx - 1 ? t : doseNx - 1;
             t = (int)ceilf(maxP.y); st->bboxMax[1] = t < doseNy - 1 ? t : doseNy - 1;
             t = (int)ceilf(maxP.z); st->bboxMax[2] = t < doseNz - 1 ? t : doseNz - 1;
+            // the BEV dose is exactly zero outside the padded rectangle [bevLo, bevHi] (+-1 px of interpolation reach): its
+            // image bounds the voxels the transfer can change
+            float txVals[2] = { (float)(st->bevLo[0] - 32 - 1), (float)(st->bevHi[0] - 32 + 1) };
+            float tyVals[2] = { (float)(st->bevLo[1] - 32 - 1), (float)(st->bevHi[1] - 32 + 1) };
+            maxP = v3(-1.0f, -1.0f, -1.0f); minP = v3(100000.0f, 100000.0f, 100000.0f);
+            for (int zi = 0; zi < 2; ++zi) for (int yi = 0; yi < 2; ++yi) for (int xi = 0; xi < 2; ++xi) {
+                Vec3 p = transformPoint(rayIdxToDoseIdx, v3(txVals[xi], tyVals[yi], zVals[zi]));
+                if (p.x > maxP.x) maxP.x = p.x; if (p.y > maxP.y) maxP.y = p.y; if (p.z > maxP.z) maxP.z = p.z;
+                if (p.x < minP.x) minP.x = p.x; if (p.y < minP.y) minP.y = p.y; if (p.z < minP.z) minP.z = p.z;
+            }
+            const int lo[3] = { (((int)floorf(minP.x) - 1) / 32) * 32,   // (aligned like the reference's box, :1207)
+                                (int)floorf(minP.y) - 1, (int)floorf(minP.z) - 1 };
+            const int hi[3] = { (int)ceilf(maxP.x) + 1, (int)ceilf(maxP.y) + 1, (int)ceilf(maxP.z) + 1 };
+            for (int i = 0; i < 3; ++i) {
+                st->tboxMin[i] = lo[i] > st->bboxMin[i] ? lo[i] : st->bboxMin[i];
+                st->tboxMax[i] = hi[i] < st->bboxMax[i] ? hi[i] : st->bboxMax[i];
+            }
         }
     }
 }
@@ -1004,25 +1035,43 @@ __global__ __launch_bounds__(256) void k_transfer(float* __restrict__ dose, int 
     const int first = st->beamFirstInside;
     const int slabZ = st->firstCalculatedPassive - first;
     if (slabZ <= 0) return;
-    const int x = st->bboxMin[0] + blockDim.x * blockIdx.x + threadIdx.x;
-    const int y = st->bboxMin[1] + blockDim.y * blockIdx.y + threadIdx.y;
-    const int xEnd = st->bboxMin[0] + ((st->bboxMax[0] - st->bboxMin[0] + 1 + 31) / 32) * 32;
-    const int z0 = st->bboxMin[2] + blockIdx.z * zChunk;
-    const int z1 = min(z0 + zChunk - 1, st->bboxMax[2]);
-    if (x >= xEnd || y > st->bboxMax[1] || x >= nx || y >= ny || z0 > z1) return;
-    TransferParams p = st->transfer;
-    p.init(x, y);
+    // The box that can receive dose is known on the device only: a fixed grid of blocks strides over its 32 x 8 x zChunk
+    // bricks (a grid over the whole dose volume would be mostly blocks that load the box and exit — measured 55 of 137 us).
+    const int bx0 = st->tboxMin[0], by0 = st->tboxMin[1], bz0 = st->tboxMin[2];
+    const int bx1 = st->tboxMax[0], by1 = st->tboxMax[1], bz1 = st->tboxMax[2];
+    if (bx1 < bx0 || by1 < by0 || bz1 < bz0) return;
+    const int nbx = (bx1 - bx0) / 32 + 1, nby = (by1 - by0) / 8 + 1, nbz = (bz1 - bz0) / zChunk + 1;
+    const int nBricks = nbx * nby * nbz;
+    const TransferParams p0 = st->transfer;
     const float* slab = bevDose + (size_t)first * fc.bevW * fc.bevH;
-    float* res = dose + (size_t)z0 * nx * ny + (size_t)y * nx + x;
     // outside this rectangle (+1 for the interpolation neighbours) every BEV slice is exactly zero: no loads needed
     const float exLo = (float)(st->bevLo[0] - 1), exHi = (float)(st->bevHi[0] + 1), eyLo = (float)(st->bevLo[1] - 1), eyHi = (float)(st->bevHi[1] + 1);
-    for (int z = z0; z <= z1; ++z) {
-        Vec3 pos = p.getFanIdx(z);
-        float tmp = 0.0f;
-        if (pos.x > exLo && pos.x < exHi && pos.y > eyLo && pos.y < eyHi)
-            tmp = sample3dBorder(slab, fc.bevW, fc.bevH, slabZ, pos.x, pos.y, pos.z);
-        if (tmp > 0.0f) *res += tmp;
-        res += (size_t)nx * ny;
+    const size_t nxy = (size_t)nx * ny;
+    for (int brick = blockIdx.x; brick < nBricks; brick += gridDim.x) {
+        const int bx = brick % nbx, by = (brick / nbx) % nby, bz = brick / (nbx * nby);
+        const int x = bx0 + 32 * bx + threadIdx.x, y = by0 + 8 * by + threadIdx.y;
+        const int z0 = bz0 + bz * zChunk, z1 = min(z0 + zChunk - 1, bz1);
+        if (x > bx1 || y > by1) continue;                            // (the box lies inside the dose grid)
+        TransferParams p = p0;
+        p.init(x, y);
+        float* res = dose + (size_t)z0 * nxy + (size_t)y * nx + x;
+        // four depth samples per trip: their 32 BEV loads are in flight together before the dose read-modify-writes
+        constexpr int kZU = 4;
+        for (int z = z0; z <= z1; z += kZU) {
+            float tmp[kZU];
+#pragma unroll
+            for (int u = 0; u < kZU; ++u) {
+                tmp[u] = 0.0f;
+                if (z + u <= z1) {
+                    Vec3 pos = p.getFanIdx(z + u);
+                    if (pos.x > exLo && pos.x < exHi && pos.y > eyLo && pos.y < eyHi)
+                        tmp[u] = sample3dBorder(slab, fc.bevW, fc.bevH, slabZ, pos.x, pos.y, pos.z);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kZU; ++u) if (tmp[u] > 0.0f) res[u * nxy] += tmp[u];
+            res += kZU * nxy;
+        }
     }
 }
 
