@@ -69,7 +69,7 @@ struct rtd_field_impl {
     std::vector<LayerPlan> hLayers;
     hipEvent_t ev[9] = {};       // 0..6 stage ends, 7 / 8 stop / start of k_superpose_mfma
     bool computed = false;
-    int ksGroups = 20;   // layer groups of the superposition (partial BEV buffers); RTD_KS_GROUPS overrides
+    int ksGroups = 14;   // layer groups of the superposition (partial BEV buffers); RTD_KS_GROUPS overrides
 };
 
 #define RTD_HIP(h, call)                                                                         \

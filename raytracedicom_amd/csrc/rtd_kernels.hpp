@@ -768,6 +768,8 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
     if (k >= st->groupPassive[g]) return;                             // no layer of this group deposits at k: the reduce skips this partial
     const int li = lane & 15, kq = lane >> 4;                         // MFMA 16x16x4: A[i=li][k=kq], B[k=kq][j=li]
     const int ox0 = tX * kKsTileX, oy0 = tY * kKsTileY;               // padded BEV coordinates of the owned tile
+    // a tile outside the rectangle that any patch of the field can reach stays unwritten: k_superpose_reduce does not read it
+    if (ox0 > st->bevHi[0] || ox0 + kKsTileX - 1 < st->bevLo[0] || oy0 > st->bevHi[1] || oy0 + kKsTileY - 1 < st->bevLo[1]) return;
     const int W = fc.W, H = fc.H;
     const size_t memStep = (size_t)W * H;
     const int nTiles = fc.tilesX * fc.tilesY;
@@ -1012,13 +1014,20 @@ __global__ __launch_bounds__(256) void k_superpose_reduce(const float* __restric
     float4* o = reinterpret_cast<float4*>(bevDose + (size_t)first * P);
     const size_t gstride = (size_t)fc.S * P / 4;
     const size_t P4 = P / 4;
+    // only the output tiles that intersect the reachable rectangle were written by k_superpose_mfma; the rest of a slice is zero
+    const int rx0 = (st->bevLo[0] / kKsTileX) * kKsTileX, rx1 = (st->bevHi[0] / kKsTileX) * kKsTileX + kKsTileX - 1;
+    const int ry0 = (st->bevLo[1] / kKsTileY) * kKsTileY, ry1 = (st->bevHi[1] / kKsTileY) * kKsTileY + kKsTileY - 1;
+    const int W4 = fc.bevW / 4;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const int k = first + (int)(i / P4);
+        const int pix = (int)(i % P4), y = pix / W4, x = (pix - y * W4) * 4;
         float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        for (int gI = 0; gI < G; ++gI) {
-            if (k >= st->groupPassive[gI]) continue;                 // this group's partial slice was not written (all zero)
-            const float4 b = p0[i + gI * gstride];
-            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        if (x >= rx0 && x <= rx1 && y >= ry0 && y <= ry1) {
+            for (int gI = 0; gI < G; ++gI) {
+                if (k >= st->groupPassive[gI]) continue;             // this group's partial slice was not written (all zero)
+                const float4 b = p0[i + gI * gstride];
+                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            }
         }
         o[i] = a;
     }
