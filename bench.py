@@ -116,10 +116,16 @@ def main():
         """One plan iteration: fresh dose volume, all kernels of this rank's field, [N>1: reduce of the union bounding box
         into rank 0, left in flight while the next plan's kernels run]."""
         d = doses[step_no[0] % len(doses)]
+        first_use = step_no[0] < len(doses)     # the volume is still the all-zero allocation
         step_no[0] += 1
-        if reducer is not None:
-            reducer.release(d)          # the reduce that used this volume two plans ago has completed
-        d.zero_()
+        view = reducer.release(d) if reducer is not None else None   # the reduce that used this volume two plans ago has completed
+        # fresh dose volume: only the voxels the previous plan wrote are cleared (rtd_field_clear_dose: the field's device-side
+        # dose box; on the reduce destination the union box that received the other ranks' dose), not all 512^3
+        if not first_use:
+            if view is not None and rank == 0:
+                view.zero_()
+            else:
+                fld.clear_dose(d.data_ptr())
         fld.compute(d.data_ptr())
         t, info = fld.finish()          # stream sync + per-stage hipEvent times + bounding box of this step
         if reducer is not None:
@@ -151,6 +157,18 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     ms_per_step = 1000.0 * elapsed / args.steps
+
+    # self-check (untimed): a volume restored by the dirty-box clear of step() must be bit-identical to the same field
+    # computed into a fully zeroed volume (compared before the pending reduce of that step is retired)
+    last = doses[(step_no[0] - 1) % len(doses)]
+    ref = torch.zeros_like(last)
+    fld.compute(ref.data_ptr())
+    fld.finish()
+    clear_ok = torch.tensor([1 if torch.equal(last, ref) else 0], dtype=torch.int64, device=dev)
+    del ref
+    if world > 1:
+        dist.all_reduce(clear_ok, op=dist.ReduceOp.MIN)
+    clear_check = bool(int(clear_ok.item()))
 
     # N>1 self-check (untimed): the reduced volume on rank 0 must hold the sum of all ranks' fields
     reduce_check = None
@@ -195,7 +213,7 @@ def main():
                        "bbox_voxels": int(np.prod([info["bbox_max"][i] - info["bbox_min"][i] + 1 for i in range(3)])),
                        "reduce": "all_gather of 6-int boxes + rccl reduce(sum) of the packed union bounding box to rank 0, overlapped with the next plan" if world > 1 else "none"},
             "ms_plan": round(ms_per_step, 4),
-            "reduce_check_rel_err": reduce_check,
+            "reduce_check_rel_err": reduce_check, "clear_check": clear_check,
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "algorithmic_bytes": alg,
             "path_gbs": round(alg["total"] / (stage_ms["total_ms"] * 1e-3) / 1e9, 2),

@@ -178,11 +178,16 @@ int rtd_compute(rtd_handle h, const rtd_beam* beams, int n_beams, float* dose_in
  * rtd_field_compute  launches every kernel of the field on the handle's stream and accumulates into
  *                    dev_dose (device memory of this handle's device). Asynchronous: no host sync,
  *                    no allocation, so it can be captured into a hipGraph;
- * rtd_field_finish   waits for the stream and reports device-side errors (radius overflow).
+ * rtd_field_finish   waits for the stream and reports device-side errors (radius overflow);
+ * rtd_field_clear_dose  zeroes, on the stream, exactly the voxels of dev_dose that the field's last
+ *                    rtd_field_compute could have changed (its device-side dose box). A plan loop that starts
+ *                    every iteration from an all-zero volume (the reference uploads a zero dose image per call,
+ *                    main.cu:192-206, kernel_wrapper.cu:542) restores it with this instead of clearing all of it.
  */
 int rtd_field_create(rtd_handle h, const rtd_beam* beam, const uint32_t dose_dims[3], rtd_field* out);
 int rtd_field_compute(rtd_handle h, rtd_field f, float* dev_dose);
 int rtd_field_finish(rtd_handle h, rtd_field f, rtd_timing* timing, rtd_field_info* info);
+int rtd_field_clear_dose(rtd_handle h, rtd_field f, float* dev_dose);
 int rtd_field_destroy(rtd_handle h, rtd_field f);
 
 /* Device buffers owned by the handle (so a C caller needs no HIP headers). */

@@ -517,6 +517,20 @@ int rtd_field_compute(rtd_handle hh, rtd_field ff, float* dev_dose) {
     return RTD_OK;
 }
 
+int rtd_field_clear_dose(rtd_handle hh, rtd_field ff, float* dev_dose) {
+    auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
+    auto* f = reinterpret_cast<rtd_field_impl*>(ff);
+    if (!h || !f || !dev_dose) return RTD_ERR_INVALID_ARG;
+    if (!f->computed) return fail(h, RTD_ERR_NOT_READY, "rtd_field_clear_dose: field not computed");
+    RTD_HIP(h, hipSetDevice(h->device));
+    const int zChunk = 16;
+    const size_t allBricks = (size_t)((f->doseDims[0] + 31) / 32) * ((f->doseDims[1] + 7) / 8) * ((f->doseDims[2] + zChunk - 1) / zChunk);
+    const unsigned g = (unsigned)std::min<size_t>(allBricks, (size_t)h->numCUs * 8 * 4);
+    k_clear_box<<<g, dim3(kSuperpTileX, kSuperpTileY), 0, h->stream>>>(dev_dose, (int)f->doseDims[0], (int)f->doseDims[1], f->dState, zChunk);
+    RTD_HIP(h, hipGetLastError());
+    return RTD_OK;
+}
+
 int rtd_field_finish(rtd_handle hh, rtd_field ff, rtd_timing* timing, rtd_field_info* info) {
     auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
     auto* f = reinterpret_cast<rtd_field_impl*>(ff);

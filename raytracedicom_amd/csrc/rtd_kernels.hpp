@@ -1084,4 +1084,21 @@ __global__ __launch_bounds__(256) void k_transfer(float* __restrict__ dose, int 
     }
 }
 
+// Zeroes the bricks of the dose box of the last transfer (rtd_field_clear_dose): same brick walk as k_transfer.
+__global__ __launch_bounds__(256) void k_clear_box(float* __restrict__ dose, int nx, int ny, const FieldState* __restrict__ st, int zChunk) {
+    const int bx0 = st->tboxMin[0], by0 = st->tboxMin[1], bz0 = st->tboxMin[2];
+    const int bx1 = st->tboxMax[0], by1 = st->tboxMax[1], bz1 = st->tboxMax[2];
+    if (bx1 < bx0 || by1 < by0 || bz1 < bz0) return;
+    const int nbx = (bx1 - bx0) / 32 + 1, nby = (by1 - by0) / 8 + 1, nbz = (bz1 - bz0) / zChunk + 1;
+    const size_t nxy = (size_t)nx * ny;
+    for (int brick = blockIdx.x; brick < nbx * nby * nbz; brick += gridDim.x) {
+        const int bx = brick % nbx, by = (brick / nbx) % nby, bz = brick / (nbx * nby);
+        const int x = bx0 + 32 * bx + threadIdx.x, y = by0 + 8 * by + threadIdx.y;
+        const int z0 = bz0 + bz * zChunk, z1 = min(z0 + zChunk - 1, bz1);
+        if (x > bx1 || y > by1) continue;
+        float* res = dose + (size_t)z0 * nxy + (size_t)y * nx + x;
+        for (int z = z0; z <= z1; ++z, res += nxy) *res = 0.0f;
+    }
+}
+
 }  // namespace rtd

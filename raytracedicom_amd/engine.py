@@ -60,6 +60,7 @@ def lib():
         L.rtd_field_create.argtypes = [vp, C.POINTER(abi.RtdBeam), u3, vpp]
         L.rtd_field_compute.argtypes = [vp, vp, vp]
         L.rtd_field_finish.argtypes = [vp, vp, C.POINTER(abi.RtdTiming), C.POINTER(abi.RtdFieldInfo)]
+        L.rtd_field_clear_dose.argtypes = [vp, vp, vp]
         L.rtd_field_destroy.argtypes = [vp, vp]
         L.rtd_field_fetch.argtypes = [vp, vp, C.c_char_p, vp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.rtd_device_alloc.argtypes = [vp, C.c_size_t, vpp]
@@ -88,6 +89,10 @@ class Field:
     def compute(self, dev_dose):
         """Launch all kernels of the field; asynchronous. dev_dose: device pointer (int) of the dose volume."""
         self.eng._check(lib().rtd_field_compute(self.eng._h, self._h, C.c_void_p(int(dev_dose))))
+
+    def clear_dose(self, dev_dose):
+        """Zero the voxels of dev_dose that the last compute() of this field could have changed; asynchronous."""
+        self.eng._check(lib().rtd_field_clear_dose(self.eng._h, self._h, C.c_void_p(int(dev_dose))))
 
     def finish(self):
         t, i = abi.RtdTiming(), abi.RtdFieldInfo()

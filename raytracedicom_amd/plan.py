@@ -76,14 +76,18 @@ class PipelinedBoxReduce:
     def _retire(self, key):
         item = self.pending.pop(key, None)
         if item is None:
-            return
+            return None
         work, view, packed = item
         work.wait()
         if self.dist.get_rank() == self.dst:
             view.copy_(packed)
+        return view
 
     def release(self, dose_tensor):
-        self._retire(id(dose_tensor))
+        """Completes the reduce that used this volume (if any) and returns the union-box view of the volume it covered
+        (None if there was none): on the destination rank that view now holds the plan's sum and is the only part of the
+        volume other ranks contributed to, so clearing it (instead of the whole volume) resets the volume."""
+        return self._retire(id(dose_tensor))
 
     def submit(self, dose_tensor, bbox_min, bbox_max):
         import torch

@@ -114,3 +114,47 @@ def test_fetch_unknown_name_and_double_finish(engine, synth):
     fld.destroy()
     eng.device_free(d)
     eng.close()
+
+
+def test_clear_dose_resets_exactly_the_written_box(engine, synth):
+    """rtd_field_clear_dose zeroes every voxel the field's compute changed (so a zero volume is zero again) and nothing
+    outside the device-side dose box (a volume pre-filled with ones keeps its ones there)."""
+    ct, _ = scenarios.hetero_phantom(96)
+    scn = scenarios.hetero_ct(synth, n=96, spots=4, pitch=7.0, n_layers=3, angles=[20.0], ct=ct)
+    n = scn.n_voxels
+    eng = engine.Engine(0)
+    eng.set_luts(scn.luts)
+    eng.set_ct(scn.ct)
+    d = eng.device_alloc(4 * n)
+    fld = eng.create_field(scn.beams[0], scn.dims)
+    with pytest.raises(engine.RtdError):
+        fld.clear_dose(d)                             # nothing computed yet
+    eng.device_zero(d, 4 * n)
+    fld.compute(d)
+    fld.finish()
+    out = np.empty(n, dtype=np.float32)
+    eng.to_host(out, d)
+    assert out.max() > 0
+    fld.clear_dose(d)
+    eng.sync()
+    eng.to_host(out, d)
+    assert not out.any()
+    ones = np.ones(n, dtype=np.float32)
+    eng.to_device(d, ones)
+    fld.compute(d)
+    _, info = fld.finish()
+    eng.to_host(out, d)
+    changed = out != 1.0
+    assert changed.any()
+    fld.clear_dose(d)
+    eng.sync()
+    eng.to_host(out, d)
+    assert (out[changed] == 0.0).all()                # everything the compute touched is cleared
+    vol = out.reshape(scn.ct.shape)
+    lo, hi = info["bbox_min"], info["bbox_max"]
+    outside = np.ones(vol.shape, dtype=bool)
+    outside[lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1] = False
+    assert (vol[outside] == 1.0).all()                # the clear stays inside the reported bounding box
+    fld.destroy()
+    eng.device_free(d)
+    eng.close()
