@@ -107,16 +107,20 @@ def main():
     # N>1: two alternating dose volumes so that the reduce of plan i (communication stream) overlaps the kernels of plan i+1
     doses = [torch.zeros((n, n, n), dtype=torch.float32, device=dev) for _ in range(2 if world > 1 else 1)]
     dose = doses[0]
-    fld = eng.create_field(beam, scn.dims)
+    # Two field objects of the same beam alternate, so plan i+1 is launched before plan i is finished (rtd_field_finish waits
+    # for its own field's last kernel only): the device does not idle while the host reads back timing and geometry.
+    flds = [eng.create_field(beam, scn.dims) for _ in range(2)]
+    fld = flds[0]
     reducer = plan.PipelinedBoxReduce(dist) if world > 1 else None
     torch.cuda.synchronize()
     step_no = [0]
+    in_flight = []                      # (field, dose volume) launched, not yet finished
 
-    def step():
-        """One plan iteration: fresh dose volume, all kernels of this rank's field, [N>1: reduce of the union bounding box
-        into rank 0, left in flight while the next plan's kernels run]."""
-        d = doses[step_no[0] % len(doses)]
-        first_use = step_no[0] < len(doses)     # the volume is still the all-zero allocation
+    def launch():
+        """Launch one plan iteration: fresh dose volume + all kernels of this rank's field (asynchronous)."""
+        i = step_no[0]
+        d, f = doses[i % len(doses)], flds[i % 2]
+        first_use = i < len(doses)              # the volume is still the all-zero allocation
         step_no[0] += 1
         view = reducer.release(d) if reducer is not None else None   # the reduce that used this volume two plans ago has completed
         # fresh dose volume: only the voxels the previous plan wrote are cleared (rtd_field_clear_dose: the field's device-side
@@ -124,13 +128,28 @@ def main():
         if not first_use:
             if view is not None and rank == 0:
                 view.zero_()
+            elif f.computed:
+                f.clear_dose(d.data_ptr())
             else:
-                fld.clear_dose(d.data_ptr())
-        fld.compute(d.data_ptr())
-        t, info = fld.finish()          # stream sync + per-stage hipEvent times + bounding box of this step
+                d.zero_()
+        f.compute(d.data_ptr())
+        in_flight.append((f, d))
+
+    def retire():
+        """Finish the oldest launched plan: wait for its last kernel, per-stage hipEvent times + bounding box, [N>1: start the
+        reduce of the union bounding box into rank 0, left in flight while later plans run]."""
+        f, d = in_flight.pop(0)
+        t, info = f.finish()
         if reducer is not None:
             reducer.submit(d, info["bbox_min"], info["bbox_max"])
         return t, info
+
+    def step():
+        """One plan iteration in steady state: launch plan i, then finish plan i-1 (pipelined by one)."""
+        launch()
+        if len(in_flight) > 1:
+            return retire()
+        return None
 
     def barrier():
         if reducer is not None:
@@ -141,17 +160,28 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    while in_flight:
+        retire()
     if reducer is not None:
         reducer.drain()
     buckets = {}
+    n_timed = 0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        t, info = step()
+        r = step()
+        if r is not None:
+            for k, v in r[0].items():
+                buckets[k] = buckets.get(k, 0.0) + float(v)
+            n_timed += 1
+    while in_flight:                    # the last plan is finished inside the timed region
+        t, info = retire()
         for k, v in t.items():
             buckets[k] = buckets.get(k, 0.0) + float(v)
+        n_timed += 1
     barrier()
     elapsed = time.perf_counter() - t0
+    assert n_timed == args.steps
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -160,6 +190,8 @@ def main():
 
     # self-check (untimed): a volume restored by the dirty-box clear of step() must be bit-identical to the same field
     # computed into a fully zeroed volume (compared before the pending reduce of that step is retired)
+    launch()
+    retire()
     last = doses[(step_no[0] - 1) % len(doses)]
     ref = torch.zeros_like(last)
     fld.compute(ref.data_ptr())
@@ -169,6 +201,8 @@ def main():
     if world > 1:
         dist.all_reduce(clear_ok, op=dist.ReduceOp.MIN)
     clear_check = bool(int(clear_ok.item()))
+    if reducer is not None:
+        reducer.drain()
 
     # N>1 self-check (untimed): the reduced volume on rank 0 must hold the sum of all ranks' fields
     reduce_check = None
@@ -251,7 +285,8 @@ def main():
                                 "max_rel_diff_above_10pct": max_rel}
             of.close()
         print(json.dumps(result))
-    fld.destroy()
+    for f in flds:
+        f.destroy()
     eng.close()
     if world > 1:
         dist.destroy_process_group()

@@ -178,7 +178,8 @@ int rtd_compute(rtd_handle h, const rtd_beam* beams, int n_beams, float* dose_in
  * rtd_field_compute  launches every kernel of the field on the handle's stream and accumulates into
  *                    dev_dose (device memory of this handle's device). Asynchronous: no host sync,
  *                    no allocation, so it can be captured into a hipGraph;
- * rtd_field_finish   waits for the stream and reports device-side errors (radius overflow);
+ * rtd_field_finish   waits for the field's last launch (not for later work on the stream) and reports device-side
+ *                    errors (radius overflow), timing and geometry of that launch;
  * rtd_field_clear_dose  zeroes, on the stream, exactly the voxels of dev_dose that the field's last
  *                    rtd_field_compute could have changed (its device-side dose box). A plan loop that starts
  *                    every iteration from an all-zero volume (the reference uploads a zero dose image per call,

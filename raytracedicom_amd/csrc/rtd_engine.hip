@@ -535,10 +535,15 @@ int rtd_field_finish(rtd_handle hh, rtd_field ff, rtd_timing* timing, rtd_field_
     auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
     auto* f = reinterpret_cast<rtd_field_impl*>(ff);
     if (!h || !f) return RTD_ERR_INVALID_ARG;
-    RTD_HIP(h, hipStreamSynchronize(h->stream));
     if (!f->computed) return fail(h, RTD_ERR_NOT_READY, "rtd_field_finish: field not computed");
+    // Wait for THIS field's last kernel only (not for the whole stream): a caller that alternates two fields can launch the
+    // next plan before finishing the previous one, and the device never idles on the host's bookkeeping. The state record is
+    // fetched on the handle's own non-blocking stream for the same reason (a plain hipMemcpy would join the caller's stream).
+    RTD_HIP(h, hipSetDevice(h->device));
+    RTD_HIP(h, hipEventSynchronize(f->ev[6]));
     FieldState st;
-    RTD_HIP(h, hipMemcpy(&st, f->dState, sizeof st, hipMemcpyDeviceToHost));
+    RTD_HIP(h, hipMemcpyAsync(&st, f->dState, sizeof st, hipMemcpyDeviceToHost, h->ownStream));
+    RTD_HIP(h, hipStreamSynchronize(h->ownStream));
     if (timing) {
         std::memset(timing, 0, sizeof *timing);
         RTD_HIP(h, hipEventElapsedTime(&timing->total_ms, f->ev[0], f->ev[6]));

@@ -85,10 +85,12 @@ class Field:
         self._h = C.c_void_p()
         ba = beam.as_abi()
         eng._check(lib().rtd_field_create(eng._h, C.byref(ba), abi.uint3(dose_dims), C.byref(self._h)))
+        self.computed = False        # a compute() has been launched (clear_dose / finish are valid)
 
     def compute(self, dev_dose):
         """Launch all kernels of the field; asynchronous. dev_dose: device pointer (int) of the dose volume."""
         self.eng._check(lib().rtd_field_compute(self.eng._h, self._h, C.c_void_p(int(dev_dose))))
+        self.computed = True
 
     def clear_dose(self, dev_dose):
         """Zero the voxels of dev_dose that the last compute() of this field could have changed; asynchronous."""

@@ -72,6 +72,7 @@ class PipelinedBoxReduce:
         self.dist = dist
         self.dst = dst
         self.pending = {}          # id(dose tensor) -> (work, view, packed)
+        self.done = {}             # id(dose tensor) -> union-box view of its last completed reduce, until release() hands it out
 
     def _retire(self, key):
         item = self.pending.pop(key, None)
@@ -81,13 +82,14 @@ class PipelinedBoxReduce:
         work.wait()
         if self.dist.get_rank() == self.dst:
             view.copy_(packed)
-        return view
+        self.done[key] = view
 
     def release(self, dose_tensor):
         """Completes the reduce that used this volume (if any) and returns the union-box view of the volume it covered
         (None if there was none): on the destination rank that view now holds the plan's sum and is the only part of the
         volume other ranks contributed to, so clearing it (instead of the whole volume) resets the volume."""
-        return self._retire(id(dose_tensor))
+        self._retire(id(dose_tensor))
+        return self.done.pop(id(dose_tensor), None)
 
     def submit(self, dose_tensor, bbox_min, bbox_max):
         import torch

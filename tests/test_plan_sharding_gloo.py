@@ -44,24 +44,36 @@ def _worker(rank, world, port, out_path, use_bbox=False):
         f.close()
 
     if use_bbox == "pipe":
-        # three plan iterations on two alternating volumes, reduces left in flight (bench.py's N>1 path)
+        # four plan iterations on two alternating volumes, reduces left in flight (bench.py's N>1 path). A reused volume is
+        # not zeroed as a whole: the destination rank clears the union box its last reduce filled, the others the box their
+        # own fields wrote; a drain() in the middle (bench.py's barrier) must not lose that bookkeeping.
         red = plan.PipelinedBoxReduce(dist, dst=0)
         vols = [np.zeros_like(scn.ct), np.zeros_like(scn.ct)]
         tens = [torch.from_numpy(v) for v in vols]
-        for it in range(3):
+        own = [None, None]
+        for it in range(4):
             v = vols[it % 2]
-            red.release(tens[it % 2])
-            v[:] = 0.0
+            view = red.release(tens[it % 2])
+            if it >= 2:
+                if view is not None and rank == 0:
+                    view.zero_()
+                else:
+                    lo, hi = own[it % 2]
+                    v[lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1] = 0.0
+                assert not v.any()
             bl, bh = [10 ** 9] * 3, [-1] * 3
             for i in plan.shard_fields(len(scn.beams), world, rank):
                 f = oracle.run_field(scn, scn.beams[i], v, keep_layers=False)
                 bl = [min(a, b) for a, b in zip(bl, f.info["bbox_min"])]
                 bh = [max(a, b) for a, b in zip(bh, f.info["bbox_max"])]
                 f.close()
+            own[it % 2] = (bl, bh)
             red.submit(tens[it % 2], bl, bh)
+            if it == 1:
+                red.drain()
         red.drain()
         dose[:] = vols[0]            # iteration 2 used volume 0
-        assert np.array_equal(vols[0], vols[1]) or rank != 0   # iteration 1 (volume 1) gives the same sum on rank 0
+        assert np.array_equal(vols[0], vols[1]) or rank != 0   # iteration 3 (volume 1) gives the same sum on rank 0
     elif use_bbox:
         for i in plan.shard_fields(len(scn.beams), world, rank):
             compute_field(i)
