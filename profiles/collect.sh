@@ -1,0 +1,22 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence quoted in DESIGN.md / bench.py on a GPU box (run from the repo root through gpurun):
+#   gpurun --timeout 900 -- 'bash profiles/collect.sh'
+# Outputs land in gpurun_out/prof/ (scratch); the summaries are then copied into profiles/ (tracked).
+# Passes are separate, as MI355X_MICROARCH.md prescribes: kernel trace + stats; --pmc FETCH_SIZE; --pmc WRITE_SIZE; SQ counters.
+set -u
+R=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$R/gpurun_out/prof
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python3 $R/bench.py --steps 20 --warmup 3 --no-cpu"
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- $BENCH > $OUT/stats.log 2>&1 || echo "stats pass failed"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o p --output-format csv -- $BENCH > $OUT/fetch.log 2>&1 || echo "fetch pass failed"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o p --output-format csv -- $BENCH > $OUT/write.log 2>&1 || echo "write pass failed"
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace -d $OUT/sq1 -o p --output-format csv -- $BENCH > $OUT/sq1.log 2>&1 || echo "sq1 pass failed"
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --kernel-trace -d $OUT/sq2 -o p --output-format csv -- $BENCH > $OUT/sq2.log 2>&1 || echo "sq2 pass failed"
+cd $R
+cp $OUT/stats/s_kernel_stats.csv $OUT/kernel_stats.csv
+python3 profiles/pmc_summary.py $OUT/fetch/p_counter_collection.csv $OUT/write/p_counter_collection.csv > $OUT/pmc_fetch_write_kb.txt
+python3 profiles/pmc_summary.py k_superpose_mfma $OUT/sq1/p_counter_collection.csv $OUT/sq2/p_counter_collection.csv > $OUT/pmc_sq_superpose.txt
+python3 profiles/pmc_summary.py --traffic-json $OUT/fetch/p_counter_collection.csv $OUT/write/p_counter_collection.csv > $OUT/traffic.json
+tail -1 $OUT/stats.log | cut -c1-400

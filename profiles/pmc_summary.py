@@ -1,19 +1,46 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc counter_collection.csv files: mean counter value per dispatch for each kernel."""
-import csv, sys, collections, re
-def main(paths, filt=None):
+"""Summarise rocprofv3 --pmc counter_collection.csv files: mean counter value per dispatch for each kernel.
+  pmc_summary.py [kernel-substring] a.csv b.csv ...      text table
+  pmc_summary.py --traffic-json fetch.csv write.csv      profiles/traffic.json (HBM bytes per launch, gfx950-corrected)"""
+import csv, sys, collections, re, json
+
+NOTE = ("HBM traffic per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, profiles/collect.sh: bench.py "
+        "--steps 20 --warmup 3, C3 workload). Units KiB. gfx950 correction: FETCH_SIZE reports half of coalesced streamed "
+        "reads (MI355X_MICROARCH.md, HBM); calibrated on this code's own kernels: k_slice_min (known 17.30 MB dword-per-lane "
+        "read) and k_superpose_reduce (known float4 reads; WRITE_SIZE matches the bytes written). "
+        "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024.")
+
+def collect(paths, filt=None):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for p in paths:
         for row in csv.DictReader(open(p)):
             k = re.sub(r"\(.*", "", row["Kernel_Name"])
             if filt and filt not in k: continue
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
-    for k, d in acc.items():
+    return acc
+
+def main(paths, filt=None):
+    for k, d in collect(paths, filt).items():
         print(k)
         for c, v in sorted(d.items()):
             print("   %-28s mean %.4g  (n=%d)" % (c, sum(v)/len(v), len(v)))
+
+def traffic(paths):
+    out = {"_note": NOTE}
+    for k, d in collect(paths).items():
+        m = re.search(r"rtd::(k_\w+)", k)
+        if not m or "FETCH_SIZE" not in d or "WRITE_SIZE" not in d: continue
+        f = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"]); w = sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
+        out[m.group(1)] = {"fetch_size_kib": round(f, 3), "write_size_kib": round(w, 3), "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
+    if "k_superpose_mfma" in out:
+        out["k_superpose"] = dict(out["k_superpose_mfma"], kernel="rtd::k_superpose_mfma")
+    print(json.dumps(out, indent=1))
+
 if __name__ == "__main__":
     args = sys.argv[1:]
-    filt = None
-    if args and not args[0].endswith(".csv"): filt, args = args[0], args[1:]
-    main(args, filt)
+    if args and args[0] == "--traffic-json":
+        traffic(args[1:])
+    else:
+        filt = None
+        if args and not args[0].endswith(".csv"): filt, args = args[0], args[1:]
+        main(args, filt)
