@@ -482,15 +482,15 @@ int rtd_field_compute(rtd_handle hh, rtd_field ff, float* dev_dose) {
                           (const LayerPlan*)f->dLayers, (const FieldState*)f->dState, fc);
     {
         const size_t fillLds = (size_t)(2 * h->lut.nSamples + h->lut.nRrl) * sizeof(float);
-        const dim3 fillGrid(rayGrid.x, rayGrid.y, fc.L);
+        const dim3 fillGrid(rayGrid.x * rayGrid.y * fc.L);              // (layer, tile) items; placement is decided in the kernel
         if (fillLds <= 96 * 1024)
             hipExtLaunchKernelGGL((k_fill<true>), fillGrid, blk, fillLds, s, nullptr, ev(3), 0, (const float*)f->dDensity, (const float*)f->dWepl, f->dIdd,
                                   f->dRSigma, (const float*)f->dRayWeights, (const int*)f->dFirstInside, (const int*)f->dFirstOutside,
-                                  f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc, (const float*)f->dStepTab, f->dActive);
+                                  f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc, (const float*)f->dStepTab, f->dActive, h->numCUs);
         else
             hipExtLaunchKernelGGL((k_fill<false>), fillGrid, blk, 0, s, nullptr, ev(3), 0, (const float*)f->dDensity, (const float*)f->dWepl, f->dIdd,
                                   f->dRSigma, (const float*)f->dRayWeights, (const int*)f->dFirstInside, (const int*)f->dFirstOutside,
-                                  f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc, (const float*)f->dStepTab, f->dActive);
+                                  f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc, (const float*)f->dStepTab, f->dActive, h->numCUs);
     }
     hipExtLaunchKernelGGL(k_ks_plan, dim3(1), dim3(64), 0, s, nullptr, ev(4), 0, f->dState, f->dLayers, fc, f->rayIdxToDoseIdx, f->transfer0,
                           (int)f->doseDims[0], (int)f->doseDims[1], (int)f->doseDims[2], f->ksGroups);

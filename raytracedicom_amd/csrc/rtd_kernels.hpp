@@ -58,6 +58,7 @@ struct FieldState {
     int groupPassive[32];           // per superposition layer group: first step at which none of its layers deposits
     int actUnion[4];                // minima of (x, y, -x, -y) over all rays that carry dose in any (layer, step)
     int bevLo[2], bevHi[2];         // padded-BEV rectangle outside which every slice is exactly zero (transfer early-out)
+    unsigned char fillOrder[256];           // energy layers by ascending number of steps to walk (k_plan), for k_fill's block placement
     unsigned char tileOrder[kKsMaxOrder];   // superposition dispatch order of the output tiles: most source rays in reach first
 };
 
@@ -93,6 +94,19 @@ __device__ inline T waveReduce(T v, Op op) {
     return __builtin_bit_cast(T, __builtin_amdgcn_readlane(x, 63));
 }
 __device__ inline float waveMin(float v) { return waveReduce(v, [](float a, float b) { return b < a ? b : a; }); }
+// minimum over each 32-lane half of the wave; valid in lanes 31 and 63 (quad_perm, row_half_mirror, row_mirror, row_bcast15)
+__device__ inline float halfWaveMin(float v) {
+    int x = __builtin_bit_cast(int, v);
+#define RTD_MIN_STEP(ctrl, rmask) { int t = __builtin_amdgcn_update_dpp(x, x, ctrl, rmask, 0xF, false); \
+                                    const float a = __builtin_bit_cast(float, x), b = __builtin_bit_cast(float, t); x = __builtin_bit_cast(int, b < a ? b : a); }
+    RTD_MIN_STEP(0xB1, 0xF)    // quad_perm [1,0,3,2]
+    RTD_MIN_STEP(0x4E, 0xF)    // quad_perm [2,3,0,1]
+    RTD_MIN_STEP(0x141, 0xF)   // row_half_mirror
+    RTD_MIN_STEP(0x140, 0xF)   // row_mirror
+    RTD_MIN_STEP(0x142, 0xA)   // row_bcast15 into rows 1 and 3
+#undef RTD_MIN_STEP
+    return __builtin_bit_cast(float, x);
+}
 __device__ inline int waveMinI(int v) { return waveReduce(v, [](int a, int b) { return b < a ? b : a; }); }
 __device__ inline int waveMaxI(int v) { return waveReduce(v, [](int a, int b) { return b > a ? b : a; }); }
 __device__ inline int f2iSat(float v) { return (int)v; }   // v_cvt_i32_f32: NaN -> 0, saturating (same as the reference GPU)
@@ -362,6 +376,14 @@ __global__ void k_plan(FieldState* st, LayerPlan* layers, const int* weplMinBits
         unsigned int g = (unsigned int)sGuaranteed;
         p.afterLast = (int)(localAfterLast < g ? localAfterLast : g);
     }
+    __syncthreads();
+    // layers ranked by the number of steps k_fill walks for them (stable rank by counting; L <= 256)
+    for (int l = threadIdx.x; l < fc.L; l += blockDim.x) {
+        const int a = layers[l].afterLast;
+        int rank = 0;
+        for (int u = 0; u < fc.L; ++u) { const int au = layers[u].afterLast; rank += (au < a || (au == a && u < l)) ? 1 : 0; }
+        st->fillOrder[rank] = (unsigned char)l;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -436,22 +458,35 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
                                                const int* __restrict__ firstOutside, int* __restrict__ firstPassive,
                                                unsigned char* __restrict__ tileRad, LayerPlan* layers, FieldState* st,
                                                LutView lut, FillGeom fg, FieldConst fc, const float* __restrict__ stepTab,
-                                               int* __restrict__ active) {
+                                               int* __restrict__ active, int nCU) {
     extern __shared__ float sLutF[];
-    __shared__ float sMin[8][4];
-    __shared__ int sAct[8][4][4];
+    __shared__ float sRs[2][8][256];                                 // [buffer][step][ray] 1/sigma of the batch's steps, for the tile minimum
+    __shared__ unsigned long long sDoseMask[2][8][4];                // [buffer][step][wave] ballot of the rays that carry dose
     __shared__ int sHist[kMaxSuperpR + 2];
 
-    const int layer = blockIdx.z;
+    // Block placement. The kernel is bound by vector-instruction throughput and the number of steps differs per layer
+    // (150..210 on C3), while only L*tiles blocks exist (2.6 per CU on C3): with a plain grid the CUs that receive 3 blocks
+    // of long layers set the kernel time and the others idle (measured: 148 CUs x 3 blocks, 108 x 2; 409 k vs 285 k cycles).
+    // When all blocks are co-resident the dispatcher places block b on CU b % nCU (measured), so the (layer, tile) items,
+    // taken in ascending order of steps, are dealt so that the CUs with one block more get the shortest items.
+    const int nTiles = fc.tilesX * fc.tilesY, nB = nTiles * fc.L;
+    int item = blockIdx.x;
+    if (nB <= 4 * nCU) {
+        const int q = nB / nCU, r = nB - q * nCU, c = blockIdx.x % nCU, rr = blockIdx.x / nCU;
+        item = c < r ? (q + 1) * c + rr : (q + 1) * r + q * (c - r) + rr;
+    } else {
+        item = nB - 1 - item;                                        // many rounds of blocks: longest first
+    }
+    const int layer = st->fillOrder[item / nTiles];
+    const int tileNo = item % nTiles, tileX = tileNo % fc.tilesX, tileY = tileNo / fc.tilesX;
     const int tid = threadIdx.y * blockDim.x + threadIdx.x;
     const int wave = tid >> 6;
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    const int x = tileX * blockDim.x + threadIdx.x;
+    const int y = tileY * blockDim.y + threadIdx.y;
     const int W = fc.W, H = fc.H;
     const size_t memStep = (size_t)W * H;
     const size_t layerOff = (size_t)layer * memStep * fc.S;
     const size_t rayIdx = (size_t)y * W + x;
-    size_t idx = rayIdx;
 
     const LayerPlan lp = layers[layer];
     // cumulative IDD: rows floor(energyIdx), floor(energyIdx)+1 (CLAMP) and the row weight are layer constants
@@ -490,22 +525,31 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
     float incScat = 0.0f, incincScat = 0.0f;
     float incDiv = lp.sigmaSqAirLin + (2.0f * (float)pFirst - 1.0f) * lp.sigmaSqAirQuad;
     float sigmaSq = -incDiv;
-    const int tileNo = blockIdx.y * gridDim.x + blockIdx.x;
-    const int nTiles = gridDim.x * gridDim.y;
     __syncthreads();
 
-    idx += (size_t)pFirst * memStep;
     int actUni = 0x7fffffff;
     constexpr int kFillBatch = 8;   // WEPL/density of a batch of steps are loaded up front (independent of the recurrence)
-    for (unsigned int step0 = pFirst; step0 < pAfterLast; step0 += kFillBatch) {
+    // WEPL / density are fetched one batch ahead of the walk (a round trip per batch was 290 cycles per step)
+    float spN[kFillBatch], denN[kFillBatch];
+    const unsigned int rayOff = (unsigned int)rayIdx;
+    auto fetch = [&](unsigned int s0) {
+#pragma unroll
+        for (int j = 0; j < kFillBatch; ++j) {                       // wave-uniform slice base + the lane's ray offset
+            spN[j] = 0.0f; denN[j] = 0.0f;
+            if (s0 + j < pAfterLast) {
+                spN[j] = (bevCumulSp + (size_t)(s0 + j) * memStep)[rayOff];
+                denN[j] = (bevDensity + (size_t)(s0 + j) * memStep)[rayOff];
+            }
+        }
+    };
+    if (pFirst < pAfterLast) fetch(pFirst);
+    int buf = 0;
+    for (unsigned int step0 = pFirst; step0 < pAfterLast; step0 += kFillBatch, buf ^= 1) {
       float spB[kFillBatch], denB[kFillBatch], rsB[kFillBatch];
       unsigned long long doseMask[kFillBatch];
 #pragma unroll
-      for (int j = 0; j < kFillBatch; ++j) {
-          const bool in = step0 + j < pAfterLast;
-          spB[j] = in ? bevCumulSp[idx + (size_t)j * memStep] : 0.0f;
-          denB[j] = in ? bevDensity[idx + (size_t)j * memStep] : 0.0f;
-      }
+      for (int j = 0; j < kFillBatch; ++j) { spB[j] = spN[j]; denB[j] = denN[j]; }
+      if (step0 + kFillBatch < pAfterLast) fetch(step0 + kFillBatch);
 #pragma unroll
       for (int j = 0; j < kFillBatch; ++j) {
         const unsigned int stepNo = step0 + j;
@@ -554,53 +598,61 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
             cumulDoseOld = cumulDose;
         }
         if (!beamLive || (int)stepNo < (firstIn - 1)) { res = 0.0f; rSigmaEff = __int_as_float(0x7f800000); }
-        bevIdd[layerOff + idx] = res;
-        bevRSigmaEff[layerOff + idx] = rSigmaEff;
+        (bevIdd + layerOff + (size_t)stepNo * memStep)[rayOff] = res;
+        (bevRSigmaEff + layerOff + (size_t)stepNo * memStep)[rayOff] = rSigmaEff;
 
         rsB[j] = rSigmaEff;
         doseMask[j] = __ballot(res > 0.0f);
-        idx += memStep;
       }
-      // fused tileRadCalc: min of 1/sigma over the 32x8 tile -> radius class of every (layer, step, tile) of the batch;
-      // one LDS exchange and one barrier per batch of steps
+      // fused tileRadCalc: min of 1/sigma over the 32x8 tile -> radius class of every (layer, step, tile) of the batch.
+      // The batch's values go through LDS once and 32 lanes per step reduce them after the barrier (eight per-wave DPP
+      // reductions per batch, one per step, cost 600 cycles per step on the walk's critical path).
 #pragma unroll
       for (int j = 0; j < kFillBatch; ++j) {
-          float wm = waveMin(rsB[j]);
-          if ((tid & (kWave - 1)) == 0) {
-              sMin[j][wave] = wm;
-              // rectangle of this wave's rays that carry dose at step j (the wave holds rows 2*wave, 2*wave+1 of the tile);
-              // stored as minima of (x, y, -x, -y)
-              const unsigned int lo = (unsigned int)doseMask[j], hi = (unsigned int)(doseMask[j] >> 32), m32 = lo | hi;
-              const int x0t = blockIdx.x * kSuperpTileX, y0w = blockIdx.y * kSuperpTileY + 2 * wave;
-              sAct[j][wave][0] = m32 ? x0t + __builtin_ctz(m32) : 0x7fffffff;
-              sAct[j][wave][1] = m32 ? y0w + (lo ? 0 : 1) : 0x7fffffff;
-              sAct[j][wave][2] = m32 ? -(x0t + 31 - __builtin_clz(m32)) : 0x7fffffff;
-              sAct[j][wave][3] = m32 ? -(y0w + (hi ? 1 : 0)) : 0x7fffffff;
+          sRs[buf][j][tid] = rsB[j];
+          if ((tid & (kWave - 1)) == 0) sDoseMask[buf][j][wave] = doseMask[j];
+      }
+      __syncthreads();                                               // the only barrier of a batch (exchange arrays are double-buffered)
+      {
+          const int j = tid >> 5, l = tid & 31;                      // step of the batch, lane of its 32-lane group
+          float m = sRs[buf][j][l];
+#pragma unroll
+          for (int k = 1; k < 8; ++k) { const float t = sRs[buf][j][l + 32 * k]; m = t < m ? t : m; }
+          m = halfWaveMin(m);                                        // lanes 31 / 63 hold the minimum of their 32-lane half
+          if (l == 31 && step0 + j < pAfterLast) {
+              int rad = f2iSat(fc.ksSigmaCutoff / (sqrtf(2.0f) * m) + 0.5f);
+              rad = rad > kMaxSuperpR + 1 ? kMaxSuperpR + 1 : rad;
+              rad = rad < 0 ? 0 : rad;
+              tileRad[((size_t)layer * fc.S + step0 + j) * nTiles + tileNo] = (unsigned char)rad;
+              atomicAdd(&sHist[rad], 1);
+          }
+          // rectangle of the tile's rays that carry dose at step j, as minima of (x, y, -x, -y): lanes 0..3 of the step's group,
+          // one component each, from the four waves' ballots (wave w holds rows 2w, 2w+1 of the tile: low / high 32 bits)
+          if (l < 4 && step0 + j < pAfterLast) {
+              unsigned int colMask = 0u, rowMask = 0u;               // columns / rows of the tile with dose
+#pragma unroll
+              for (int w = 0; w < 4; ++w) {
+                  const unsigned long long dm = sDoseMask[buf][j][w];
+                  const unsigned int lo = (unsigned int)dm, hi = (unsigned int)(dm >> 32);
+                  colMask |= lo | hi;
+                  rowMask |= (lo ? 1u : 0u) << (2 * w) | (hi ? 1u : 0u) << (2 * w + 1);
+              }
+              if (colMask) {
+                  const int x0t = tileX * kSuperpTileX, y0t = tileY * kSuperpTileY;
+                  const int v = l == 0 ? x0t + __builtin_ctz(colMask) : l == 1 ? y0t + __builtin_ctz(rowMask)
+                              : l == 2 ? -(x0t + 31 - __builtin_clz(colMask)) : -(y0t + 31 - __builtin_clz(rowMask));
+                  atomicMin(&active[((size_t)layer * fc.S + step0 + j) * 4 + l], v);
+                  actUni = min(actUni, v);
+              }
           }
       }
-      __syncthreads();
-      if (tid < kFillBatch && step0 + tid < pAfterLast) {
-          float m = sMin[tid][0];
-          m = sMin[tid][1] < m ? sMin[tid][1] : m; m = sMin[tid][2] < m ? sMin[tid][2] : m; m = sMin[tid][3] < m ? sMin[tid][3] : m;
-          int rad = f2iSat(fc.ksSigmaCutoff / (sqrtf(2.0f) * m) + 0.5f);
-          rad = rad > kMaxSuperpR + 1 ? kMaxSuperpR + 1 : rad;
-          rad = rad < 0 ? 0 : rad;
-          tileRad[((size_t)layer * fc.S + step0 + tid) * nTiles + tileNo] = (unsigned char)rad;
-          atomicAdd(&sHist[rad], 1);
-      }
-      if (tid >= 32 && tid < 32 + 4 * kFillBatch) {                  // 4 lanes per step of the batch: one component each
-          const int j = (tid - 32) >> 2, c = (tid - 32) & 3;
-          const int v = min(min(sAct[j][0][c], sAct[j][1][c]), min(sAct[j][2][c], sAct[j][3][c]));
-          if (step0 + j < pAfterLast && v != 0x7fffffff) { atomicMin(&active[((size_t)layer * fc.S + step0 + j) * 4 + c], v); actUni = min(actUni, v); }
-      }
-      __syncthreads();
     }
     firstPassive[(size_t)layer * memStep + rayIdx] = (int)afterLast;
     int mx = waveMaxI((int)afterLast);
     if ((tid & (kWave - 1)) == 0) atomicMax(&layers[layer].layerFirstPassive, mx);
     __syncthreads();
     if (tid < kMaxSuperpR + 2 && sHist[tid] > 0) atomicAdd(&layers[layer].hist[tid], sHist[tid]);
-    if (tid >= 32 && tid < 32 + 4 * kFillBatch && actUni != 0x7fffffff) atomicMin(&st->actUnion[(tid - 32) & 3], actUni);
+    if ((tid & 31) < 4 && actUni != 0x7fffffff) atomicMin(&st->actUnion[tid & 3], actUni);
 }
 
 // ------------------------------------------------------------------------------------------------
