@@ -62,6 +62,7 @@ struct rtd_field_impl {
     float *dDensity = nullptr, *dWepl = nullptr, *dIdd = nullptr, *dRSigma = nullptr, *dBev = nullptr, *dBevPart = nullptr;
     int *dFirstInside = nullptr, *dFirstOutside = nullptr, *dFirstPassive = nullptr, *dWeplMin = nullptr;
     unsigned char* dTileRad = nullptr;
+    size_t tileRadWords = 0;
     LayerPlan* dLayers = nullptr;
     float* dStepTab = nullptr;
     int* dActive = nullptr;      // [L][S][4] minima of (x, y, -x, -y) over rays with dose > 0
@@ -424,7 +425,8 @@ int rtd_field_create(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dims[
     A(&f->dSpotWeights, nSpot); A(&f->dConvInterm, (size_t)W * b->spot_ny * L); A(&f->dRayWeights, R * L);
     A(&f->dDensity, R * S); A(&f->dWepl, R * S); A(&f->dIdd, R * S * L); A(&f->dRSigma, R * S * L); A(&f->dBev, P * S); A(&f->dBevPart, P * S * f->ksGroups);
     A(&f->dFirstInside, R); A(&f->dFirstOutside, R); A(&f->dFirstPassive, R * L); A(&f->dWeplMin, (size_t)S);
-    A(&f->dTileRad, (size_t)L * S * tilesX * tilesY); A(&f->dLayers, (size_t)L); A(&f->dState, (size_t)1); A(&f->dStepTab, (size_t)2 * S); A(&f->dActive, (size_t)4 * L * S);
+    f->tileRadWords = ((size_t)L * S * tilesX * tilesY + 3) / 4;      // filled as 32-bit words by k_reset
+    A(&f->dTileRad, f->tileRadWords * 4); A(&f->dLayers, (size_t)L); A(&f->dState, (size_t)1); A(&f->dStepTab, (size_t)2 * S); A(&f->dActive, (size_t)4 * L * S);
     if (st != RTD_OK) { rtd_field_destroy(hh, reinterpret_cast<rtd_field>(f)); return st; }
     hipError_t e = hipMemcpy(f->dSpotWeights, b->spot_weights, nSpot * sizeof(float), hipMemcpyHostToDevice);   // :851
     if (e == hipSuccess) e = hipMemcpy(f->dLayers, f->hLayers.data(), (size_t)L * sizeof(LayerPlan), hipMemcpyHostToDevice);
@@ -461,7 +463,8 @@ int rtd_field_compute(rtd_handle hh, rtd_field ff, float* dev_dose) {
     // Stage boundaries are the start / stop timestamps of the kernels themselves (hipExtLaunchKernelGGL), not event
     // packets between them: no barrier packet and no idle gap is inserted into the stream by the timing.
     auto ev = [&](int i) -> hipEvent_t { return timing ? f->ev[i] : nullptr; };
-    hipExtLaunchKernelGGL(k_reset, dim3(1), dim3(256), 0, s, f->ev[0], nullptr, 0, f->dState, f->dLayers, fc.L);
+    hipExtLaunchKernelGGL(k_reset, dim3(64), dim3(256), 0, s, f->ev[0], nullptr, 0, f->dState, f->dLayers, fc.L,
+                          reinterpret_cast<unsigned int*>(f->dTileRad), f->tileRadWords, f->dActive, (size_t)4 * fc.L * fc.S);
     const size_t lutLds = (size_t)(h->lut.nDensity + h->lut.nSp) * sizeof(float);
     // dIdd doubles as the HU scratch of the tracer (it is written by k_fill only afterwards)
     k_trace_sample<<<dim3((unsigned)(f->R / 256), (fc.S + kTraceSeg - 1) / kTraceSeg), 256, lutLds, s>>>(
@@ -475,8 +478,6 @@ int rtd_field_compute(rtd_handle hh, rtd_field ff, float* dev_dose) {
                                                      f->dState);
     hipExtLaunchKernelGGL(k_slice_min, dim3(fc.S), dim3(256), 0, s, nullptr, ev(1), 0, (const float*)f->dWepl, (size_t)f->R, f->dWeplMin);
     k_plan<<<1, 64, 0, s>>>(f->dState, f->dLayers, f->dWeplMin, fc);
-    RTD_HIP(h, hipMemsetAsync(f->dTileRad, kNoRadius, (size_t)fc.L * fc.S * fc.tilesX * fc.tilesY, s));
-    RTD_HIP(h, hipMemsetAsync(f->dActive, 0x7f, (size_t)4 * fc.L * fc.S * sizeof(int), s));   // +large: empty rectangles
     k_conv_x<<<dim3(fc.W / 32, (fc.spotNy + 7) / 8, fc.L), blk, 0, s>>>(f->dSpotWeights, f->dConvInterm, f->dLayers, f->dState, fc);
     hipExtLaunchKernelGGL(k_conv_y, dim3(fc.W / 32, fc.H / 8, fc.L), blk, 0, s, nullptr, ev(2), 0, (const float*)f->dConvInterm, f->dRayWeights,
                           (const LayerPlan*)f->dLayers, (const FieldState*)f->dState, fc);

@@ -172,8 +172,9 @@ __device__ inline float sample3dBorder(const float* __restrict__ vol, int nx, in
 
 // ------------------------------------------------------------------------------------------------
 // K0: reset the per-field device state (the reference re-creates these per beam, kernel_wrapper.cu:685-734).
-__global__ void k_reset(FieldState* st, LayerPlan* layers, int L) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void k_reset(FieldState* st, LayerPlan* layers, int L, unsigned int* __restrict__ tileRadWords, size_t nRadWords,
+                        int* __restrict__ active, size_t nActive) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nT = (size_t)gridDim.x * blockDim.x;
     if (t == 0) {
         st->beamFirstInside = 0x7fffffff; st->beamFirstOutside = -0x7fffffff; st->firstGuaranteedPassive = 0;
         st->firstCalculatedPassive = 0; st->errorFlags = 0; st->maxRadius = 0; st->liveSteps = 0;
@@ -181,10 +182,13 @@ __global__ void k_reset(FieldState* st, LayerPlan* layers, int L) {
         for (int i = 0; i < 4; ++i) st->actUnion[i] = 0x7fffffff;
         for (int i = 0; i < 3; ++i) { st->bboxMin[i] = 0; st->bboxMax[i] = 0; st->tboxMin[i] = 0; st->tboxMax[i] = -1; }
     }
-    for (int l = t; l < L; l += gridDim.x * blockDim.x) {
+    for (size_t l = t; l < (size_t)L; l += nT) {
         layers[l].layerFirstPassive = 0; layers[l].afterLast = 0;
         for (int i = 0; i < kMaxSuperpR + 2; ++i) { layers[l].hist[i] = 0; layers[l].effRad[i] = i; }
     }
+    // (the two fills the reference does with cudaMemset per layer, kernel_wrapper.cu:824-827, in the same launch)
+    for (size_t i = t; i < nRadWords; i += nT) tileRadWords[i] = 0xFFFFFFFFu;      // every (layer, step, tile): "not classified"
+    for (size_t i = t; i < nActive; i += nT) active[i] = 0x7f7f7f7f;               // empty dose rectangles (+large minima)
 }
 
 // ------------------------------------------------------------------------------------------------
