@@ -858,7 +858,7 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
         }
         rho = waveMaxI(rho);
         if (rho < 0) continue;                                       // wave-uniform
-        const int Tm = rho + 1, T = 2 * Tm + 1;                      // mirrored table m[u], u = d + Tm, d in [-Tm, Tm]; m[+-Tm] = 0
+        const int Tm = rho + 1, T = Tm + 1;                          // one-sided table m[u], u = |d| in [0, Tm]; m[Tm] = 0 (weights are even in d)
         // source window = reach of the tile, clipped to the ray grid and to the rectangle of rays that carry dose at this
         // (layer, step) (recorded by k_fill): margins of dead rays are never scanned
         const int* act = active + ((size_t)layer * fc.S + k) * 4;
@@ -880,13 +880,13 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
             sy = ry0 + r; sx = cx0 + (i0 - r * nCols);
         }
         const int xEnd = cx0 + nCols;
-        // Per-visit address arithmetic is done in LDS byte addresses: operand address = clamp(laneConst + visitScalar,
-        // table centre -4Tm, +4Tm) = one v_add + one v_med3 per operand (the clamp lands on the zero ends of the table
-        // when a lane's row/column is out of the source's reach).
+        // Per-visit operand addressing: entry u = min(|lane coordinate - source coordinate|, Tm) of the lane's source table
+        // (entry Tm is the zero guard: a lane whose row / column is out of the source's reach reads 0) = v_sad_u32 + v_min_u32 +
+        // v_lshl_add_u32 per operand. Coordinates carry a bias (64 rows, 128 columns) so that they are unsigned.
         const int ldsBase = (int)(size_t)(__attribute__((address_space(3))) float*)lds;   // LDS byte address of the slice
-        const int laneTab = ldsBase + (kq * T + Tm) * 4;             // + 16*q*T: centre of the lane's source table
-        const int laneA = laneTab + (oy0 + li - 32) * 4;             // + 64*t - 4*qRow
-        const int laneB = laneTab + (ox0 + li - kq - 32 - cx0) * 4;  // + 64*t - 4*qCol
+        const int laneTab = ldsBase + kq * T * 4;                    // + 16*q*T: the lane's source table (source kq of the quad)
+        const int laneRow = oy0 + li - 32 + 64;                      // + 16*t: output row of the lane in source-row coordinates
+        const int laneCol = ox0 + li - kq - 32 - cx0 + 128;          // + 16*t: output column minus the lane's source offset in the quad (window-relative)
         const int laneD = ldsBase + (CS * T + kq) * 4;               // + 16*q: the lane's dose
         // dose and 1/sigma of a chunk are fetched one chunk ahead (one memory round trip, hidden behind the previous chunk)
         const float* __restrict__ iddSlice = bevIdd + sliceOff;
@@ -934,8 +934,6 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
             if (lane < CS) {
                 dArr[lane] = dose;
                 float* m = lds + lane * T;
-                float* mp = m + Tm;
-                float* mn = m + Tm;
                 if (rhoS >= 0 && rs <= 0.5f) {
                     // Pixel-integrated Gaussian weights e_i = (1/2)(erf(rs(i+1/2)) - erf(rs(i-1/2))) (kernel_wrapper.cuh:459-467)
                     // evaluated as the Taylor series of the integral around the pixel centre x = rs*i:
@@ -954,9 +952,9 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
                     const float c3 = 64.0f * k3 * (h4 * h2);
                     float q = expf(-h2), gq = 0.5641895835f * rs;    // gq = rs/sqrt(pi) * exp(-x_i^2)
                     const float cq = q * q;
-                    // two entries per trip (T = 2 Tm + 1 is odd: entry 0 first), so the LDS stores use immediate offsets
+                    // two entries per trip (entry 0 first), so the LDS stores use immediate offsets
                     const float e0 = c0 * gq;
-                    *mp = e0;
+                    m[0] = e0;
                     gq *= q; q *= cq;
                     for (int i = 1; i <= Tm; i += 2) {
                         const float w0 = (float)(i * i), w1 = (float)((i + 1) * (i + 1));
@@ -966,8 +964,8 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
                         const float ea = i <= rhoS ? gq * s0 : 0.0f;
                         const float eb = i + 1 <= rhoS ? g1 * s1 : 0.0f;
                         gq = g1 * q1; q = q1 * cq;
-                        mp[i] = ea; mp[-i] = ea;
-                        if (i + 1 <= Tm) { mp[i + 1] = eb; mp[-i - 1] = eb; }
+                        m[i] = ea;
+                        if (i + 1 <= Tm) m[i + 1] = eb;
                     }
                 } else {
                     float erfNew = 0.0f, erfOld = 0.0f;
@@ -979,8 +977,7 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
                             erfOld = erfNew;
                             erfNew = erff(rs * ((float)i + 1.5f));
                         }
-                        *mp++ = e;
-                        *mn-- = e;
+                        m[i] = e;
                     }
                 }
             }
@@ -995,26 +992,24 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
                 live &= ~(0xFull << q4);
                 const int qi = __builtin_amdgcn_readlane(qinfo, q4);
                 const int qm = qi & 0xFF, qRow4 = (qi >> 6) & 0x3FFC, qCol4 = (int)(((unsigned)qi >> 18) & 0x3FFC);
-                const int tabOff = q4 * T * 4;                       // scalar
-                const int ctr = laneTab + tabOff, lo = ctr - 4 * Tm, hi = ctr + 4 * Tm;
-                const int sa = tabOff - qRow4, sb = tabOff - qCol4;
+                const int ctr = laneTab + q4 * T * 4;                // byte address of entry 0 of the lane's source table
+                const int qRowB = (qRow4 >> 2) + 64, qColB = (qCol4 >> 2) + 128;  // scalar, biased
                 typedef __attribute__((address_space(3))) const float* lptr;
                 const float dl = *(lptr)(size_t)(laneD + 4 * q4);
-                // operands are fetched only for the tile rows / columns the quad reaches (qm): A = dose * m[row - y_s]
+                auto entry = [&](int laneCoord, int srcCoord) -> float {
+                    unsigned int u;
+                    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(u) : "v"(laneCoord), "s"(srcCoord));
+                    u = u < (unsigned)Tm ? u : (unsigned)Tm;
+                    return *(lptr)(size_t)(ctr + (int)(u << 2));
+                };
+                // operands are fetched only for the tile rows / columns the quad reaches (qm): A = dose * m[|row - y_s|]
                 float a0, a1;                                        // each is read only under the mask bits that set it
-                if (qm & 0x0F) {
-                    int ad; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(ad) : "v"(laneA + sa), "v"(lo), "v"(hi));
-                    a0 = dl * *(lptr)(size_t)ad;
-                }
-                if (qm & 0xF0) {
-                    int ad; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(ad) : "v"(laneA + (sa + 64)), "v"(lo), "v"(hi));
-                    a1 = dl * *(lptr)(size_t)ad;
-                }
+                if (qm & 0x0F) a0 = dl * entry(laneRow, qRowB);
+                if (qm & 0xF0) a1 = dl * entry(laneRow + 16, qRowB);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     if (qm & (0x11 << t)) {
-                        int ad; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(ad) : "v"(laneB + (sb + 64 * t)), "v"(lo), "v"(hi));
-                        const float bt = *(lptr)(size_t)ad;
+                        const float bt = entry(laneCol + 16 * t, qColB);
                         if (qm & (1 << t)) acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bt, acc[0][t], 0, 0, 0);
                         if (qm & (16 << t)) acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bt, acc[1][t], 0, 0, 0);
                     }
