@@ -121,6 +121,15 @@ def test_heterogeneous_rotated_divergent(orc, engine, synth, deg, dist):
     _compare_field(orc, engine, scn, scn.beams[0])
 
 
+def test_wide_field_many_tiles(orc, engine, synth):
+    """A field wider than the CT: 448 x 448 rays -> 128 superposition output tiles (> the 64 that get a work-ranked dispatch
+    order) and 1568 fill blocks (> 4 per CU: the plain longest-first placement); every intermediate still matches."""
+    ct, _ = scenarios.hetero_phantom(64)
+    scn = scenarios.hetero_ct(synth, n=64, spots=70, pitch=6.0, n_layers=2, angles=[0.0], steps=160, ct=ct)
+    _, _, _, info = _compare_field(orc, engine, scn, scn.beams[0])
+    assert info["ray_dims"][0] * info["ray_dims"][1] >= 400 * 400
+
+
 def test_options_switches(orc, engine, synth):
     """DOSE_TO_WATER off, NO_NOZZLE, different cut-offs (CMakeLists.txt:36-79) follow the oracle too."""
     ct, _ = scenarios.hetero_phantom(96)
