@@ -63,7 +63,7 @@ def test_cpp_shim_and_example_compile(tmp_path):
     if not os.path.exists(engine.LIB_PATH):
         engine.build()
     exe = str(tmp_path / "water_cube")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "examples"),
                            os.path.join(ROOT, "examples", "water_cube_main.cpp"), "-L", os.path.join(ROOT, "raytracedicom_amd"),
                            "-lrtd_hip", "-Wl,-rpath," + os.path.join(ROOT, "raytracedicom_amd"), "-o", exe])
     import torch
@@ -71,6 +71,51 @@ def test_cpp_shim_and_example_compile(tmp_path):
         r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "lut_small") + "/", str(tmp_path), "16", "1"],
                            capture_output=True, text=True)
         assert r.returncode == 1 and "no CPU fallback" in r.stderr
+
+
+def _build_cli(tmp_path):
+    exe = str(tmp_path / "raytracedicom")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "examples"),
+                           os.path.join(ROOT, "examples", "raytracedicom_main.cpp"), "-L", os.path.join(ROOT, "raytracedicom_amd"),
+                           "-lrtd_hip", "-Wl,-rpath," + os.path.join(ROOT, "raytracedicom_amd"), "-o", exe])
+    return exe
+
+
+def test_cli_flag_surface_of_the_reference(tmp_path):
+    """examples/raytracedicom_main.cpp: the reference's flags (config.cpp:13-51) — required arguments, existing file / directory
+    checks, --config_file overridden by the command line, the echoed configuration; DICOM input stops with exit code 3."""
+    if not os.path.exists(engine.LIB_PATH):
+        engine.build()
+    exe = _build_cli(tmp_path)
+    luts = os.path.join(ROOT, "tests", "golden", "lut_small")
+    out = str(tmp_path / "out"); os.mkdir(out)
+    run = lambda *a: subprocess.run([exe, *a], capture_output=True, text=True)
+    assert run("--help").returncode == 0 and "--output_directory" in run("--help").stdout
+    r = run("--water_cube", "--lut_dir", luts)
+    assert r.returncode == 2 and "--output_directory is required" in r.stderr
+    r = run("--water_cube", "--lut_dir", luts, "--output_directory", str(tmp_path / "missing"))
+    assert r.returncode == 2 and "Directory does not exist" in r.stderr
+    r = run("--output_directory", out, "--lut_dir", luts)
+    assert r.returncode == 2 and "--ct_dir is required" in r.stderr
+    r = run("--output_directory", out, "--lut_dir", luts, "--ct_dir", out, "--rtplan", str(tmp_path / "nope.dcm"), "--beams", "G000")
+    assert r.returncode == 2 and "File does not exist" in r.stderr
+    r = run("--output_directory", out, "--bogus", "1")
+    assert r.returncode == 2 and "not expected" in r.stderr
+    r = run("--output_directory", out, "--gpu_id", "-1", "--water_cube")
+    assert r.returncode == 2 and "could not convert" in r.stderr
+    plan = str(tmp_path / "plan.dcm"); open(plan, "wb").write(b"\0" * 132)
+    cfg = str(tmp_path / "run.ini")
+    open(cfg, "w").write("# run parameters\noutput_directory = \"%s\"\nlut_dir=%s\nct_dir = %s ; series\nrtplan = %s\nbeams = [\"G000\", \"G090\"]\ngpu_id=3\n"
+                         % (out, luts, out, plan))
+    r = run("--config_file", cfg)
+    assert r.returncode == 1 and "Multi-beam calculation not yet supported" in r.stderr       # main.cu:117-120
+    assert 'beams=["G000", "G090"]' in r.stdout and "gpu_id=3" in r.stdout
+    r = run("--config_file", cfg, "--beams", "G000", "--gpu_id", "0")                         # the command line overrides the file
+    assert r.returncode == 3 and "DICOM input" in r.stderr and 'beams=["G000"]' in r.stdout and "gpu_id=0" in r.stdout
+    import torch
+    if not torch.cuda.is_available():
+        r = run("--config_file", cfg, "--water_cube", "--water_cube_edge", "16", "--layers", "1", "--gpu_id", "0")
+        assert r.returncode == 1 and "no CPU fallback" in r.stderr and "water_cube=true" in r.stdout
 
 
 def test_product_path_never_imports_the_oracle():

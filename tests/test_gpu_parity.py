@@ -212,7 +212,8 @@ def test_cpp_shim_water_cube_driver(engine, synth, tmp_path):
     d = str(tmp_path / "luts")
     luts.write_lut_dir(d, synth)
     exe = str(tmp_path / "water_cube")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "water_cube_main.cpp"),
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "examples"),
+                           os.path.join(ROOT, "examples", "water_cube_main.cpp"),
                            "-L", os.path.join(ROOT, "raytracedicom_amd"), "-lrtd_hip", "-Wl,-rpath," + os.path.join(ROOT, "raytracedicom_amd"), "-o", exe])
     r = subprocess.run([exe, d + "/", str(tmp_path), "64", "2"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
@@ -222,3 +223,17 @@ def test_cpp_shim_water_cube_driver(engine, synth, tmp_path):
     prof = dose[:, 32, 32]
     depth = 128.0 - (4.0 * int(prof.argmax()) - 106.0)     # 4 mm voxels; beam starts at z = 128 mm
     assert 90.0 < depth < 125.0                               # Bragg peaks of the first two layers (~100-105 mm)
+    # the reference's flag surface (examples/raytracedicom_main.cpp, config.cpp:13-51) drives the same plan: identical file
+    cli = str(tmp_path / "raytracedicom")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "examples"),
+                           os.path.join(ROOT, "examples", "raytracedicom_main.cpp"),
+                           "-L", os.path.join(ROOT, "raytracedicom_amd"), "-lrtd_hip", "-Wl,-rpath," + os.path.join(ROOT, "raytracedicom_amd"), "-o", cli])
+    out2 = tmp_path / "cli_out"
+    out2.mkdir()
+    cfg = tmp_path / "run.ini"
+    cfg.write_text("output_directory = \"%s\"\nlut_dir = %s\nwater_cube = true\nwater_cube_edge = 32\nlayers = 2\n" % (out2, d))
+    r2 = subprocess.run([cli, "--config_file", str(cfg), "--water_cube_edge", "64", "--gpu_id", "0"], capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0, r2.stderr
+    assert "water_cube_edge=64" in r2.stdout and "Max:" in r2.stdout
+    dose2 = np.fromfile(str(out2 / "dose.dat"), dtype=np.float32)
+    assert np.array_equal(dose2, dose.ravel())
