@@ -67,6 +67,8 @@ struct rtd_field_impl {
     float* dStepTab = nullptr;
     int* dActive = nullptr;      // [L][S][4] minima of (x, y, -x, -y) over rays with dose > 0
     FieldState* dState = nullptr;
+    FieldState* hState = nullptr;      // pinned host mirror of *dState (written by k_ks_plan), and its device-side address
+    FieldState* dHostState = nullptr;
     std::vector<LayerPlan> hLayers;
     hipEvent_t ev[9] = {};       // 0..6 stage ends, 7 / 8 stop / start of k_superpose_mfma
     bool computed = false;
@@ -113,6 +115,13 @@ bool readTokens(const std::string& path, std::vector<double>& out) {
 }
 
 }  // namespace
+
+// Launch with optional start / stop events taken from the kernel's own dispatch timestamps (hipExtLaunchKernelGGL): no
+// event packets between kernels. (Measured alternative: plain launches bracketed by hipEventRecord, +25 us per field.)
+template <typename K, typename... Args>
+static void launchK(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t s, hipEvent_t startEv, hipEvent_t stopEv, Args... args) {
+    hipExtLaunchKernelGGL(kernel, grid, block, lds, s, startEv, stopEv, 0, args...);
+}
 
 extern "C" {
 
@@ -327,6 +336,7 @@ int rtd_field_destroy(rtd_handle hh, rtd_field ff) {
                      f->dFirstInside, f->dFirstOutside, f->dFirstPassive, f->dWeplMin, f->dTileRad,
                      f->dLayers, f->dState, f->dStepTab, f->dActive };
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (f->hState) (void)hipHostFree(f->hState);
     for (auto& e : f->ev) if (e) (void)hipEventDestroy(e);
     delete f;
     return RTD_OK;
@@ -431,6 +441,8 @@ int rtd_field_create(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dims[
     hipError_t e = hipMemcpy(f->dSpotWeights, b->spot_weights, nSpot * sizeof(float), hipMemcpyHostToDevice);   // :851
     if (e == hipSuccess) e = hipMemcpy(f->dLayers, f->hLayers.data(), (size_t)L * sizeof(LayerPlan), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(f->dState, 0, sizeof(FieldState));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&f->hState, sizeof(FieldState), hipHostMallocMapped);
+    if (e == hipSuccess) { std::memset(f->hState, 0, sizeof(FieldState)); e = hipHostGetDevicePointer((void**)&f->dHostState, f->hState, 0); }
     {
         std::vector<float> tab(2 * (size_t)S);
         for (int k = 0; k < S; ++k) {
@@ -449,6 +461,7 @@ int rtd_field_create(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dims[
 }
 
 // The beam loop body as launches only (kernel_wrapper.cu:766-1218). Asynchronous on the handle's stream.
+
 int rtd_field_compute(rtd_handle hh, rtd_field ff, float* dev_dose) {
     auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
     auto* f = reinterpret_cast<rtd_field_impl*>(ff);
@@ -463,7 +476,7 @@ int rtd_field_compute(rtd_handle hh, rtd_field ff, float* dev_dose) {
     // Stage boundaries are the start / stop timestamps of the kernels themselves (hipExtLaunchKernelGGL), not event
     // packets between them: no barrier packet and no idle gap is inserted into the stream by the timing.
     auto ev = [&](int i) -> hipEvent_t { return timing ? f->ev[i] : nullptr; };
-    hipExtLaunchKernelGGL(k_reset, dim3(64), dim3(256), 0, s, f->ev[0], nullptr, 0, f->dState, f->dLayers, fc.L,
+    launchK(k_reset, dim3(64), dim3(256), 0, s, f->ev[0], nullptr, f->dState, f->dLayers, fc.L,
                           reinterpret_cast<unsigned int*>(f->dTileRad), f->tileRadWords, f->dActive, (size_t)4 * fc.L * fc.S);
     const size_t lutLds = (size_t)(h->lut.nDensity + h->lut.nSp) * sizeof(float);
     // dIdd doubles as the HU scratch of the tracer (it is written by k_fill only afterwards)
@@ -476,33 +489,33 @@ int rtd_field_compute(rtd_handle hh, rtd_field ff, float* dev_dose) {
     }
     k_trace_scan<<<(unsigned)(f->R / 64), dim3(64, kScanWaves), scanLds, s>>>(f->dIdd, f->dWepl, fc.W, fc.H, (unsigned)fc.S, f->dFirstInside, f->dFirstOutside,
                                                      f->dState);
-    hipExtLaunchKernelGGL(k_slice_min, dim3(fc.S), dim3(256), 0, s, nullptr, ev(1), 0, (const float*)f->dWepl, (size_t)f->R, f->dWeplMin);
+    launchK(k_slice_min, dim3(fc.S), dim3(256), 0, s, nullptr, ev(1), (const float*)f->dWepl, (size_t)f->R, f->dWeplMin);
     k_plan<<<1, 64, 0, s>>>(f->dState, f->dLayers, f->dWeplMin, fc);
     k_conv_x<<<dim3(fc.W / 32, (fc.spotNy + 7) / 8, fc.L), blk, 0, s>>>(f->dSpotWeights, f->dConvInterm, f->dLayers, f->dState, fc);
-    hipExtLaunchKernelGGL(k_conv_y, dim3(fc.W / 32, fc.H / 8, fc.L), blk, 0, s, nullptr, ev(2), 0, (const float*)f->dConvInterm, f->dRayWeights,
+    launchK(k_conv_y, dim3(fc.W / 32, fc.H / 8, fc.L), blk, 0, s, nullptr, ev(2), (const float*)f->dConvInterm, f->dRayWeights,
                           (const LayerPlan*)f->dLayers, (const FieldState*)f->dState, fc);
     {
         const size_t fillLds = (size_t)(2 * h->lut.nSamples + h->lut.nRrl) * sizeof(float);
         const dim3 fillGrid(rayGrid.x * rayGrid.y * fc.L);              // (layer, tile) items; placement is decided in the kernel
         if (fillLds <= 96 * 1024)
-            hipExtLaunchKernelGGL((k_fill<true>), fillGrid, blk, fillLds, s, nullptr, ev(3), 0, (const float*)f->dDensity, (const float*)f->dWepl, f->dIdd,
+            launchK((k_fill<true>), fillGrid, blk, fillLds, s, nullptr, ev(3), (const float*)f->dDensity, (const float*)f->dWepl, f->dIdd,
                                   f->dRSigma, (const float*)f->dRayWeights, (const int*)f->dFirstInside, (const int*)f->dFirstOutside,
                                   f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc, (const float*)f->dStepTab, f->dActive, h->numCUs);
         else
-            hipExtLaunchKernelGGL((k_fill<false>), fillGrid, blk, 0, s, nullptr, ev(3), 0, (const float*)f->dDensity, (const float*)f->dWepl, f->dIdd,
+            launchK((k_fill<false>), fillGrid, blk, 0, s, nullptr, ev(3), (const float*)f->dDensity, (const float*)f->dWepl, f->dIdd,
                                   f->dRSigma, (const float*)f->dRayWeights, (const int*)f->dFirstInside, (const int*)f->dFirstOutside,
                                   f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc, (const float*)f->dStepTab, f->dActive, h->numCUs);
     }
-    hipExtLaunchKernelGGL(k_ks_plan, dim3(1), dim3(64), 0, s, nullptr, ev(4), 0, f->dState, f->dLayers, fc, f->rayIdxToDoseIdx, f->transfer0,
-                          (int)f->doseDims[0], (int)f->doseDims[1], (int)f->doseDims[2], f->ksGroups);
+    launchK(k_ks_plan, dim3(1), dim3(64), 0, s, nullptr, ev(4), f->dState, f->dLayers, fc, f->rayIdxToDoseIdx, f->transfer0,
+                          (int)f->doseDims[0], (int)f->doseDims[1], (int)f->doseDims[2], f->ksGroups, f->dHostState);
     {
         const int nTX = (fc.bevW + kKsTileX - 1) / kKsTileX, nTY = (fc.bevH + kKsTileY - 1) / kKsTileY;
         const int G = f->ksGroups;
         const int nItems = fc.S * G * nTY * nTX;
-        hipExtLaunchKernelGGL(k_superpose_mfma, dim3(nItems), dim3(64 * kKsSplit), 0, s, ev(8), ev(7), 0, (const float*)f->dIdd, (const float*)f->dRSigma,
+        launchK(k_superpose_mfma, dim3(nItems), dim3(64 * kKsSplit), 0, s, ev(8), ev(7), (const float*)f->dIdd, (const float*)f->dRSigma,
                               f->dBevPart, (const unsigned char*)f->dTileRad, (const LayerPlan*)f->dLayers, (const FieldState*)f->dState, fc, nTX, nTY, G,
                               (const int*)f->dActive);
-        hipExtLaunchKernelGGL(k_superpose_reduce, dim3(1024), dim3(256), 0, s, nullptr, ev(5), 0, (const float*)f->dBevPart, f->dBev,
+        launchK(k_superpose_reduce, dim3(1024), dim3(256), 0, s, nullptr, ev(5), (const float*)f->dBevPart, f->dBev,
                               (const FieldState*)f->dState, fc, G);
     }
     const int zChunk = 16;
@@ -510,7 +523,7 @@ int rtd_field_compute(rtd_handle hh, rtd_field ff, float* dev_dose) {
         // grid-stride over the bricks of the device-side box; never more blocks than bricks of the whole volume
         const size_t allBricks = (size_t)((f->doseDims[0] + 31) / 32) * ((f->doseDims[1] + 7) / 8) * ((f->doseDims[2] + zChunk - 1) / zChunk);
         const unsigned tg = (unsigned)std::min<size_t>(allBricks, (size_t)h->numCUs * 8 * 4);
-        hipExtLaunchKernelGGL(k_transfer, dim3(tg), blk, 0, s, nullptr, f->ev[6], 0, dev_dose, (int)f->doseDims[0], (int)f->doseDims[1],
+        launchK(k_transfer, dim3(tg), blk, 0, s, nullptr, f->ev[6], dev_dose, (int)f->doseDims[0], (int)f->doseDims[1],
                               (int)f->doseDims[2], (const float*)f->dBev, (const FieldState*)f->dState, fc, zChunk);
     }
     RTD_HIP(h, hipGetLastError());
@@ -538,13 +551,11 @@ int rtd_field_finish(rtd_handle hh, rtd_field ff, rtd_timing* timing, rtd_field_
     if (!h || !f) return RTD_ERR_INVALID_ARG;
     if (!f->computed) return fail(h, RTD_ERR_NOT_READY, "rtd_field_finish: field not computed");
     // Wait for THIS field's last kernel only (not for the whole stream): a caller that alternates two fields can launch the
-    // next plan before finishing the previous one, and the device never idles on the host's bookkeeping. The state record is
-    // fetched on the handle's own non-blocking stream for the same reason (a plain hipMemcpy would join the caller's stream).
+    // next plan before finishing the previous one, and the device never idles on the host's bookkeeping. The state record was
+    // mirrored into pinned host memory by k_ks_plan: no copy is issued here.
     RTD_HIP(h, hipSetDevice(h->device));
     RTD_HIP(h, hipEventSynchronize(f->ev[6]));
-    FieldState st;
-    RTD_HIP(h, hipMemcpyAsync(&st, f->dState, sizeof st, hipMemcpyDeviceToHost, h->ownStream));
-    RTD_HIP(h, hipStreamSynchronize(h->ownStream));
+    const FieldState st = *f->hState;                                // mirrored by k_ks_plan into pinned host memory
     if (timing) {
         std::memset(timing, 0, sizeof *timing);
         RTD_HIP(h, hipEventElapsedTime(&timing->total_ms, f->ev[0], f->ev[6]));

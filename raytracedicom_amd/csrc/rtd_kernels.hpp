@@ -663,7 +663,7 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
 // K6: superposition plan = host batching of radii (kernel_wrapper.cu:965-976) + beamFirstCalculatedPassive
 // (:955-957) + transfer bounding box and shift (:1185-1213), all on the device.
 __global__ void k_ks_plan(FieldState* st, LayerPlan* layers, FieldConst fc, FromFan rayIdxToDoseIdx, TransferParams tp0,
-                          int doseNx, int doseNy, int doseNz, int G) {
+                          int doseNx, int doseNy, int doseNz, int G, FieldState* __restrict__ hostMirror) {
     __shared__ int sMaxPassive;
     __shared__ int sGroup[32];
     __shared__ int sMaxRad;
@@ -773,7 +773,13 @@ __global__ void k_ks_plan(FieldState* st, LayerPlan* layers, FieldConst fc, From
             }
         }
     }
+    // The state record is final here (the kernels after this one only read it): thread 0 mirrors it into pinned host
+    // memory, so rtd_field_finish needs no device-to-host copy (a copy on a second stream stalled the compute queue for
+    // ~37 us per field, measured).
+    __syncthreads();
+    if (threadIdx.x == 0 && hostMirror) { __threadfence(); *hostMirror = *st; __threadfence_system(); }
 }
+
 
 // ------------------------------------------------------------------------------------------------
 // K7: output-stationary kernel superposition on the matrix cores, one autonomous WAVE per work item.
