@@ -16,6 +16,10 @@
 //   --lut_dir DIR           directory of the LUT text files (default: $RTD_LUT_DIR, then ./LUTs/)
 //   --water_cube            run the reference's WATER_CUBE_TEST plan (main.cu:39-99) instead of reading DICOM input
 //   --water_cube_edge N     voxels per cube edge (default 256)      --layers N   energy layers (default 20)
+//   --spot_list FILE        with --water_cube: the plan is read from a spot-list text file (E x y fwhm_x fwhm_y meterset rows,
+//                           gantry_angle / isocenter / source_dist keys) and turned into BeamSettings by include/rtd_plan.hpp
+//                           (the step the reference's main.cu:150-197 stops before)
+//   --dump_spot_list FILE   write the built-in water-cube plan as such a spot list and exit
 // The parsed configuration is echoed as key=value lines like the reference's app.config_to_str (config.cpp:62).
 // DICOM input (--ct_dir/--rtplan without --water_cube) is SURVEY §8 row f3 and not built yet: the run stops with a
 // message, exit code 3 — the reference's own DICOM path stops after printing the plan, with zero spot weights
@@ -31,7 +35,7 @@ namespace {
 
 struct Config {
     unsigned short gpu_id = 0;
-    std::string ct_dir, rtplan, output_directory, lut_dir;
+    std::string ct_dir, rtplan, output_directory, lut_dir, spot_list, dump_spot_list;
     std::vector<std::string> beams;
     bool water_cube = false;
     unsigned int water_cube_edge = 256, layers = 20;
@@ -79,7 +83,9 @@ void printHelp() {
                  "  --lut_dir TEXT:DIR          Directory of the LUT text files (default $RTD_LUT_DIR, then ./LUTs/).\n"
                  "  --water_cube                Run the reference's WATER_CUBE_TEST plan instead of reading DICOM input.\n"
                  "  --water_cube_edge UINT      Voxels per cube edge (256).\n"
-                 "  --layers UINT               Energy layers of the water-cube plan (20).\n";
+                 "  --layers UINT               Energy layers of the water-cube plan (20).\n"
+                 "  --spot_list TEXT:FILE       With --water_cube: plan from a spot-list text file (E x y fwhm_x fwhm_y meterset).\n"
+                 "  --dump_spot_list TEXT       Write the built-in water-cube plan as a spot list and exit.\n";
 }
 
 unsigned long parseUInt(const std::string& key, const std::string& v, unsigned long maxV) {
@@ -100,6 +106,8 @@ void assign(Config& c, const std::string& key, const std::vector<std::string>& v
     else if (key == "rtplan") c.rtplan = one();
     else if (key == "output_directory") c.output_directory = one();
     else if (key == "lut_dir") c.lut_dir = one();
+    else if (key == "spot_list") c.spot_list = one();
+    else if (key == "dump_spot_list") c.dump_spot_list = one();
     else if (key == "beams") { if (vals.empty()) usageError("--beams: At least 1 required"); c.beams = vals; }
     else if (key == "water_cube") {
         if (vals.empty()) c.water_cube = true;
@@ -141,6 +149,7 @@ std::string configToStr(const Config& c) {                            // like CL
     o << "water_cube=" << (c.water_cube ? "true" : "false") << "\n";
     o << "water_cube_edge=" << c.water_cube_edge << "\n";
     o << "layers=" << c.layers << "\n";
+    o << "spot_list=\"" << c.spot_list << "\"\n";
     return o.str();
 }
 
@@ -189,6 +198,8 @@ int main(int argc, char** argv) {
         if (!seen.count("beams")) usageError("--beams is required");
     }
     if (!isDir(config.lut_dir)) usageError("--lut_dir: Directory does not exist: " + config.lut_dir);
+    if (!config.spot_list.empty() && !isFile(config.spot_list)) usageError("--spot_list: File does not exist: " + config.spot_list);
+    if (!config.spot_list.empty() && !config.water_cube) usageError("--spot_list requires --water_cube (CT input is not built yet)");
     std::cout << configToStr(config) << std::endl;
 
     if (!config.water_cube) {
@@ -198,6 +209,15 @@ int main(int argc, char** argv) {
         return 3;
     }
     try {
+        if (!config.dump_spot_list.empty()) {
+            EnergyStruct ciddData = energyReader(config.lut_dir, /*waterCubeTest=*/true);
+            writeSpotList(config.dump_spot_list, waterCubeSpots(ciddData, config.layers), rtd_plan::FieldGeometry());
+            std::cout << "Written " << config.dump_spot_list << std::endl;
+            return 0;
+        }
+        if (!config.spot_list.empty())
+            runSpotListOnWaterCube(config.lut_dir, config.output_directory, config.water_cube_edge, config.spot_list, (int)config.gpu_id);
+        else
         runWaterCube(config.lut_dir, config.output_directory, config.water_cube_edge, config.layers, (int)config.gpu_id);
     } catch (const std::exception& e) {
         std::cerr << "error: " << e.what() << std::endl;

@@ -1,0 +1,54 @@
+"""RT ion plan spot list -> BeamSettings (include/rtd_plan.hpp), the step the reference's main.cu stops
+before (main.cu:150-197). CPU: the C++ unit checks of tests/cpp/test_rtd_plan.cpp. GPU: the reference's water-cube field
+written as a spot list and read back through the CLI gives the dose of the built-in plan."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from raytracedicom_amd import engine
+
+
+def _cxx(src, exe, extra=()):
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "examples"),
+                           src, "-L", os.path.join(ROOT, "raytracedicom_amd"), "-lrtd_hip", "-Wl,-rpath," + os.path.join(ROOT, "raytracedicom_amd"),
+                           "-o", exe, *extra])
+
+
+def test_spot_list_to_beam_settings(tmp_path):
+    if not os.path.exists(engine.LIB_PATH):
+        engine.build()
+    exe = str(tmp_path / "test_rtd_plan")
+    _cxx(os.path.join(ROOT, "tests", "cpp", "test_rtd_plan.cpp"), exe)
+    r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "lut_small") + "/", str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0 and "rtd_plan ok" in r.stdout, r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_spot_list_reproduces_the_builtin_plan(synth, tmp_path):
+    from raytracedicom_amd import luts
+    d = str(tmp_path / "luts")
+    luts.write_lut_dir(d, synth)
+    cli = str(tmp_path / "raytracedicom")
+    _cxx(os.path.join(ROOT, "examples", "raytracedicom_main.cpp"), cli)
+    outs = []
+    for name in ("builtin", "spots"):
+        o = tmp_path / name
+        o.mkdir()
+        outs.append(o)
+    base = [cli, "--water_cube", "--water_cube_edge", "64", "--layers", "3", "--lut_dir", d]
+    r = subprocess.run(base + ["--output_directory", str(outs[0])], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    spots = str(tmp_path / "spots.txt")
+    r = subprocess.run(base + ["--output_directory", str(outs[1]), "--dump_spot_list", spots], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and os.path.exists(spots), r.stderr
+    r = subprocess.run(base + ["--output_directory", str(outs[1]), "--spot_list", spots], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "3267 spots in 3 layer(s) on a 33x33 spot grid" in r.stdout
+    a = np.fromfile(str(outs[0] / "dose.dat"), dtype=np.float32)
+    b = np.fromfile(str(outs[1] / "dose.dat"), dtype=np.float32)
+    assert a.max() > 0
+    # sigma -> FWHM -> sigma costs an ulp; everything else is identical
+    np.testing.assert_allclose(b, a, rtol=2e-5, atol=1e-7 * float(a.max()))
