@@ -111,7 +111,7 @@ def main():
     # for its own field's last kernel only): the device does not idle while the host reads back timing and geometry.
     flds = [eng.create_field(beam, scn.dims) for _ in range(2)]
     fld = flds[0]
-    reducer = plan.PipelinedBoxReduce(dist) if world > 1 else None
+    reducer = plan.PipelinedBoxReduce(dist, static_boxes=True) if world > 1 else None   # the fields keep their geometry
     torch.cuda.synchronize()
     step_no = [0]
     in_flight = []                      # (field, dose volume) launched, not yet finished
@@ -122,16 +122,16 @@ def main():
         d, f = doses[i % len(doses)], flds[i % 2]
         first_use = i < len(doses)              # the volume is still the all-zero allocation
         step_no[0] += 1
-        view = reducer.release(d) if reducer is not None else None   # the reduce that used this volume two plans ago has completed
+        views = reducer.release(d) if reducer is not None else None  # the exchange that used this volume two plans ago has completed
         # fresh dose volume: only the voxels the previous plan wrote are cleared (rtd_field_clear_dose: the field's device-side
-        # dose box; on the reduce destination the union box that received the other ranks' dose), not all 512^3
+        # dose box; on the destination rank also the boxes that received the other ranks' dose), not all 512^3
         if not first_use:
-            if view is not None and rank == 0:
-                view.zero_()
-            elif f.computed:
+            if f.computed:
                 f.clear_dose(d.data_ptr())
             else:
                 d.zero_()
+            for v in views or ():
+                v.zero_()
         f.compute(d.data_ptr())
         in_flight.append((f, d))
 
@@ -141,7 +141,7 @@ def main():
         f, d = in_flight.pop(0)
         t, info = f.finish()
         if reducer is not None:
-            reducer.submit(d, info["bbox_min"], info["bbox_max"])
+            reducer.submit(d, info["dose_box_min"], info["dose_box_max"])
         return t, info
 
     def step():
@@ -213,7 +213,7 @@ def main():
         fld.compute(d.data_ptr())
         _, chk_info = fld.finish()
         local_sum = d.sum(dtype=torch.float64).reshape(1)
-        reducer.submit(d, chk_info["bbox_min"], chk_info["bbox_max"])
+        reducer.submit(d, chk_info["dose_box_min"], chk_info["dose_box_max"])
         reducer.drain()
         dist.all_reduce(local_sum, op=dist.ReduceOp.SUM)
         if rank == 0:
@@ -245,7 +245,7 @@ def main():
                                    "10x10 spots x 20 layers = 2000 spots, 512 tracer steps, 1 mm rays" % (n, world),
                        "ray_grid": info["ray_dims"], "live_steps": info["live_steps"], "max_radius": info["max_radius"],
                        "bbox_voxels": int(np.prod([info["bbox_max"][i] - info["bbox_min"][i] + 1 for i in range(3)])),
-                       "reduce": "all_gather of 6-int boxes + rccl reduce(sum) of the packed union bounding box to rank 0, overlapped with the next plan" if world > 1 else "none"},
+                       "reduce": "each rank sends its packed dose box (rtd_field_info.dose_box) to rank 0 (rccl send/recv over its own xGMI link), rank 0 adds the N-1 boxes; overlapped with the next plan" if world > 1 else "none"},
             "ms_plan": round(ms_per_step, 4),
             "reduce_check_rel_err": reduce_check, "clear_check": clear_check,
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RTD_ABI_VERSION 1
+#define RTD_ABI_VERSION 2
 
 typedef enum rtd_status {
     RTD_OK = 0,
@@ -133,7 +133,9 @@ typedef struct rtd_field_info {
     int32_t bbox_max[3];          /* kernel_wrapper.cu:1208 */
     int64_t live_steps;           /* sum over layers of (layerFirstPassive - beamFirstInside) */
     int32_t max_radius;           /* largest tile radius over all layers */
-    int32_t reserved[3];
+    int32_t dose_box_min[3];      /* sub-box of bbox that this field can have changed: the image of the BEV rectangle that */
+    int32_t dose_box_max[3];      /* carries dose (what rtd_field_clear_dose clears; what a multi-GPU plan has to send)     */
+    int32_t reserved[1];
 } rtd_field_info;
 
 typedef struct rtd_handle_s* rtd_handle;

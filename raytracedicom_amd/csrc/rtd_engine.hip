@@ -578,6 +578,7 @@ int rtd_field_finish(rtd_handle hh, rtd_field ff, rtd_timing* timing, rtd_field_
         info->beam_first_guaranteed_passive = st.firstGuaranteedPassive;
         info->beam_first_calculated_passive = st.firstCalculatedPassive;
         for (int i = 0; i < 3; ++i) { info->bbox_min[i] = st.bboxMin[i]; info->bbox_max[i] = st.bboxMax[i]; }
+        for (int i = 0; i < 3; ++i) { info->dose_box_min[i] = st.tboxMin[i]; info->dose_box_max[i] = st.tboxMax[i]; }
         info->live_steps = st.liveSteps; info->max_radius = st.maxRadius;
     }
     if (st.errorFlags & kErrRadiusOverflow)

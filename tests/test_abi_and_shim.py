@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 25
     for n in names:
         assert hasattr(lib, n), "librtd_hip.so does not export %s" % n
-    assert engine.lib().rtd_abi_version() == 1
+    assert engine.lib().rtd_abi_version() == 2
 
 
 def test_struct_sizes_match_header():

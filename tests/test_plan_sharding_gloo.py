@@ -31,7 +31,7 @@ def _worker(rank, world, port, out_path, use_bbox=False):
     oracle.set_threads(2)
     es = luts.synth_luts()
     ct, _ = scenarios.hetero_phantom(64)
-    scn = scenarios.hetero_ct(es, n=64, spots=4, pitch=8.0, n_layers=2, angles=[0.0, 90.0], ct=ct)
+    scn = scenarios.hetero_ct(es, n=64, spots=4, pitch=8.0, n_layers=2, angles=[0.0, 90.0, 200.0][:max(2, world)], ct=ct)
     dose = np.zeros_like(scn.ct)
     t = torch.from_numpy(dose)
 
@@ -45,21 +45,20 @@ def _worker(rank, world, port, out_path, use_bbox=False):
 
     if use_bbox == "pipe":
         # four plan iterations on two alternating volumes, reduces left in flight (bench.py's N>1 path). A reused volume is
-        # not zeroed as a whole: the destination rank clears the union box its last reduce filled, the others the box their
-        # own fields wrote; a drain() in the middle (bench.py's barrier) must not lose that bookkeeping.
+        # not zeroed as a whole: every rank clears the box its own fields wrote, the destination rank also the boxes it received
+        # from the others; a drain() in the middle (bench.py's barrier) must not lose that bookkeeping.
         red = plan.PipelinedBoxReduce(dist, dst=0)
         vols = [np.zeros_like(scn.ct), np.zeros_like(scn.ct)]
         tens = [torch.from_numpy(v) for v in vols]
         own = [None, None]
         for it in range(4):
             v = vols[it % 2]
-            view = red.release(tens[it % 2])
+            views = red.release(tens[it % 2])
             if it >= 2:
-                if view is not None and rank == 0:
-                    view.zero_()
-                else:
-                    lo, hi = own[it % 2]
-                    v[lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1] = 0.0
+                lo, hi = own[it % 2]
+                v[lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1] = 0.0     # what this rank's own fields wrote
+                for w in views or ():                                        # (destination) what the other ranks' boxes added
+                    w.zero_()
                 assert not v.any()
             bl, bh = [10 ** 9] * 3, [-1] * 3
             for i in plan.shard_fields(len(scn.beams), world, rank):
@@ -88,18 +87,18 @@ def _worker(rank, world, port, out_path, use_bbox=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("use_bbox", [False, True, "pipe"])
-def test_two_rank_plan_equals_sequential(orc, synth, tmp_path, use_bbox):
+@pytest.mark.parametrize("use_bbox,world", [(False, 2), (True, 2), ("pipe", 2), ("pipe", 3)])
+def test_sharded_plan_equals_sequential(orc, synth, tmp_path, use_bbox, world):
     import torch.multiprocessing as mp
     from raytracedicom_amd import scenarios
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = str(tmp_path / "dose.npy")
-    mp.spawn(_worker, args=(2, port, out, use_bbox), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, out, use_bbox), nprocs=world, join=True)
     got = np.load(out)
     ct, _ = scenarios.hetero_phantom(64)
-    scn = scenarios.hetero_ct(synth, n=64, spots=4, pitch=8.0, n_layers=2, angles=[0.0, 90.0], ct=ct)
+    scn = scenarios.hetero_ct(synth, n=64, spots=4, pitch=8.0, n_layers=2, angles=[0.0, 90.0, 200.0][:max(2, world)], ct=ct)
     ref = orc.compute(scn)
     assert ref.max() > 0
     np.testing.assert_allclose(got, ref, rtol=1e-6, atol=1e-12 * float(ref.max()))
