@@ -21,9 +21,11 @@
 //                           (the step the reference's main.cu:150-197 stops before)
 //   --dump_spot_list FILE   write the built-in water-cube plan as such a spot list and exit
 // The parsed configuration is echoed as key=value lines like the reference's app.config_to_str (config.cpp:62).
-// DICOM input (--ct_dir/--rtplan without --water_cube) is SURVEY §8 row f3 and not built yet: the run stops with a
-// message, exit code 3 — the reference's own DICOM path stops after printing the plan, with zero spot weights
-// (main.cu:105-190).
+// Without --water_cube the CT series and the RT Ion Plan are read by include/rtd_dicom.hpp (no ITK / GDCM), the named beams —
+// one or several, where the reference throws "Multi-beam calculation not yet supported" (main.cu:117-120) — become
+// BeamSettings through include/rtd_plan.hpp and their dose is written to dose.dat on the CT grid. The reference's own DICOM
+// path stops after printing the plan, with zero spot weights (main.cu:105-190).
+//   --start_depth MM / --tracer_steps N   override the tracer range that is otherwise fitted to the CT along each beam axis
 #include <sys/stat.h>
 
 #include <map>
@@ -39,6 +41,8 @@ struct Config {
     std::vector<std::string> beams;
     bool water_cube = false;
     unsigned int water_cube_edge = 256, layers = 20;
+    float start_depth = 0.0f;       // DICOM mode: gantry z of tracer step 0 (0 = just upstream of the CT)
+    unsigned int tracer_steps = 0;  // DICOM mode: 0 = as many as it takes to cross the CT
 };
 
 bool isDir(const std::string& p) { struct stat st; return ::stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode); }
@@ -84,6 +88,8 @@ void printHelp() {
                  "  --water_cube                Run the reference's WATER_CUBE_TEST plan instead of reading DICOM input.\n"
                  "  --water_cube_edge UINT      Voxels per cube edge (256).\n"
                  "  --layers UINT               Energy layers of the water-cube plan (20).\n"
+                 "  --start_depth FLOAT         DICOM input: gantry z (mm) of tracer step 0 (default: just upstream of the CT).\n"
+                 "  --tracer_steps UINT         DICOM input: number of 1 mm tracer steps (default: enough to cross the CT).\n"
                  "  --spot_list TEXT:FILE       With --water_cube: plan from a spot-list text file (E x y fwhm_x fwhm_y meterset).\n"
                  "  --dump_spot_list TEXT       Write the built-in water-cube plan as a spot list and exit.\n";
 }
@@ -115,6 +121,8 @@ void assign(Config& c, const std::string& key, const std::vector<std::string>& v
     }
     else if (key == "water_cube_edge") c.water_cube_edge = (unsigned int)parseUInt(key, one(), 4096);
     else if (key == "layers") c.layers = (unsigned int)parseUInt(key, one(), 256);
+    else if (key == "tracer_steps") c.tracer_steps = (unsigned int)parseUInt(key, one(), 4096);
+    else if (key == "start_depth") { char* end = nullptr; c.start_depth = std::strtof(one().c_str(), &end); if (*end) usageError("--start_depth: not a number"); }
     else usageError("The following argument was not expected: --" + key);
     seen[key] = true;
 }
@@ -202,13 +210,12 @@ int main(int argc, char** argv) {
     if (!config.spot_list.empty() && !config.water_cube) usageError("--spot_list requires --water_cube (CT input is not built yet)");
     std::cout << configToStr(config) << std::endl;
 
-    if (!config.water_cube) {
-        if (config.beams.size() > 1) { std::cerr << "error: Multi-beam calculation not yet supported" << std::endl; return 1; }   // main.cu:117-120
-        std::cerr << "error: DICOM input (CT series + RT ion plan) is not built yet (SURVEY.md section 8, rows f2/f3); "
-                     "run with --water_cube for the reference's WATER_CUBE_TEST plan" << std::endl;
-        return 3;
-    }
     try {
+        if (!config.water_cube) {                                       // DICOM input (SURVEY section 8 rows f2 + f3)
+            runDicomPlan(config.lut_dir, config.output_directory, config.ct_dir, config.rtplan, config.beams, (int)config.gpu_id,
+                         config.start_depth, (int)config.tracer_steps);
+            return 0;
+        }
         if (!config.dump_spot_list.empty()) {
             EnergyStruct ciddData = energyReader(config.lut_dir, /*waterCubeTest=*/true);
             writeSpotList(config.dump_spot_list, waterCubeSpots(ciddData, config.layers), rtd_plan::FieldGeometry());

@@ -12,6 +12,7 @@
 
 #include <sstream>
 
+#include "rtd_dicom.hpp"
 #include "rtd_plan.hpp"
 #include "rtd_types.hpp"
 #include "rtd_wrapper.hpp"
@@ -124,6 +125,57 @@ inline void readSpotList(const std::string& path, std::vector<rtd_plan::Spot>& s
         else if (key == "start_depth") { need(1); g.startDepth = v[0]; }
         else throw std::runtime_error(path + ":" + std::to_string(lineNo) + ": unknown key " + key);
     }
+}
+
+// Dose of the named beams of an RT Ion Plan on a DICOM CT series (what the reference's non-WATER_CUBE_TEST build is meant to do,
+// main.cu:100-216): CT -> HU+1000 + imIdxToWorld (dicom_reader.cpp), beams -> BeamSettings (rtd_plan.hpp), dose grid = CT grid.
+// startDepth / tracerSteps <= 0 mean "cover the CT along the beam axis".
+inline void runDicomPlan(const std::string& lutDir, const std::string& outDir, const std::string& ctDir, const std::string& planFile,
+                         const std::vector<std::string>& beamNamesIn, int gpuId, float startDepth, int tracerSteps, std::vector<float>* doseOut = nullptr) {
+    clock_t t = clock();
+    EnergyStruct ciddData = energyReader(lutDir, /*waterCubeTest=*/false);
+    std::cout << "Read energy matrix: " << static_cast<float>(clock() - t) / CLOCKS_PER_SEC << " seconds.\n\n";
+    t = clock();
+    rtd_dicom::CtVolume ct = rtd_dicom::readCtSeries(ctDir);
+    std::cout << "Read image: " << static_cast<float>(clock() - t) / CLOCKS_PER_SEC << " seconds (series " << ct.seriesUid << ", " << ct.dim.x << "x" << ct.dim.y
+              << "x" << ct.dim.z << ")\n\n";
+    if (!ct.patientPosition.empty() && ct.patientPosition != "HFS") throw std::runtime_error("patient position " + ct.patientPosition + " is not supported (HFS only)");
+    const rtd_dicom::File plan = rtd_dicom::readFile(planFile);
+    std::vector<float> dose(ct.huPlus1000.size(), 0.0f);
+    HostPinnedImage3D<float> doseVol(dose.data(), ct.dim), imVol(ct.huPlus1000.data(), ct.dim);
+    std::vector<rtd_plan::BuiltField> fields;
+    std::vector<std::vector<float>> weightStore;
+    std::vector<std::unique_ptr<HostPinnedImage3D<float>>> weightImages;
+    std::vector<BeamSettings> beams;
+    for (size_t i = 0; i < beamNamesIn.size(); ++i) {
+        std::cout << "Loading field " << i << " corresponding to beamname " << beamNamesIn[i] << std::endl;                    // main.cu:122
+        rtd_dicom::PlanBeam b = rtd_dicom::readPlanBeam(plan, beamNamesIn[i]);
+        std::cout << "Angles: " << b.beamLimitingDeviceAngleDeg << " " << b.geo.gantryAngleDeg << " " << b.patientSupportAngleDeg << " deg" << std::endl;  // :151
+        std::cout << "IsoCenter: " << b.geo.isocenter.x << " " << b.geo.isocenter.y << " " << b.geo.isocenter.z << " mm" << std::endl;
+        std::cout << "ImgPixels: " << ct.dim.x << " " << ct.dim.y << " " << ct.dim.z << std::endl;
+        b.geo.hasGantryToWorld = true;
+        b.geo.gantryToWorld = rtd_dicom::gantryToPatientHfs(b.geo.gantryAngleDeg, b.patientSupportAngleDeg, b.geo.isocenter);
+        rtd_dicom::tracerRange(ct, b.geo.gantryToWorld, b.geo.stepLength, b.geo.startDepth, b.geo.tracerSteps);
+        if (startDepth > 0.0f) b.geo.startDepth = startDepth;
+        if (tracerSteps > 0) b.geo.tracerSteps = (unsigned int)tracerSteps;
+        fields.push_back(rtd_plan::buildField(b.spots, b.geo, ct.imIdxToWorld, ct.imIdxToWorld));
+        std::cout << b.spots.size() << " spots in " << fields.back().dims.z << " layer(s) on a " << fields.back().dims.x << "x" << fields.back().dims.y
+                  << " spot grid; tracer: " << b.geo.tracerSteps << " steps of " << b.geo.stepLength << " mm from " << b.geo.startDepth << " mm\n\n";
+    }
+    for (auto& f : fields) {
+        weightStore.push_back(f.weights);
+        weightImages.emplace_back(new HostPinnedImage3D<float>(weightStore.back().data(), f.dims));
+        beams.push_back(f.beamSettings(weightImages.back().get()));
+    }
+    std::cout << "Executing code on GPU...\n\n";
+    cudaWrapperProtons(&imVol, &doseVol, beams, ciddData, std::cout, gpuId);
+    std::cout << "Done!\n\n";
+    std::ofstream fout((outDir + "/dose.dat").c_str(), std::ios::out | std::ios::binary);                                       // main.cu:211-216
+    fout.write(reinterpret_cast<const char*>(dose.data()), dose.size() * sizeof(float));
+    fout.close();
+    std::cout << "Written " << outDir << "/dose.dat with size " << ct.dim.x << "x" << ct.dim.y << "x" << ct.dim.z << "\n\n";
+    std::cout << "Max:" << *std::max_element(dose.begin(), dose.end()) << std::endl;
+    if (doseOut) *doseOut = dose;
 }
 
 // Dose of a plan given as a spot list on the water cube (CT input proper is SURVEY section 8 row f3).

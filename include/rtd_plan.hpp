@@ -44,6 +44,8 @@ struct FieldGeometry {
     unsigned int tracerSteps = 512;
     float stepLength = 1.0f;                                          // mm per tracer step (beam travels along -z)
     float startDepth = 128.0f;                                        // gantry z of tracer step 0 (mm upstream of the isocentre)
+    bool hasGantryToWorld = false;                                    // true: gantryToWorld below replaces the rotation-about-Y convention
+    Float3AffineTransform gantryToWorld;                              //       (rtd_dicom.hpp sets the IEC 61217 / DICOM patient one)
 };
 
 // Owns the arrays a BeamSettings points to.
@@ -134,7 +136,8 @@ inline BuiltField buildField(const std::vector<Spot>& spots, const FieldGeometry
         f.sigmas[l] = make_float2((float)(mx * fwhmToSigma), (float)(my * fwhmToSigma));
     }
     f.spotIdxToGantry = Float3IdxTransform(make_float3(px, py, -geo.stepLength), make_float3(x0, y0, geo.startDepth));
-    const Float3AffineTransform gantryToWorld(detail::rotationY(geo.gantryAngleDeg), geo.isocenter);
+    const Float3AffineTransform gantryToWorld = geo.hasGantryToWorld ? geo.gantryToWorld
+                                                                      : Float3AffineTransform(detail::rotationY(geo.gantryAngleDeg), geo.isocenter);
     f.gantryToImIdx = concatFloat3AffineTransform(gantryToWorld, imIdxToWorld.inverse());       // main.cu:55-57
     f.gantryToDoseIdx = concatFloat3AffineTransform(gantryToWorld, doseIdxToWorld.inverse());
     return f;

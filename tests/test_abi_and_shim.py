@@ -83,7 +83,7 @@ def _build_cli(tmp_path):
 
 def test_cli_flag_surface_of_the_reference(tmp_path):
     """examples/raytracedicom_main.cpp: the reference's flags (config.cpp:13-51) — required arguments, existing file / directory
-    checks, --config_file overridden by the command line, the echoed configuration; DICOM input stops with exit code 3."""
+    checks, --config_file overridden by the command line, the echoed configuration; DICOM input is parsed before the engine is needed."""
     if not os.path.exists(engine.LIB_PATH):
         engine.build()
     exe = _build_cli(tmp_path)
@@ -103,17 +103,31 @@ def test_cli_flag_surface_of_the_reference(tmp_path):
     assert r.returncode == 2 and "not expected" in r.stderr
     r = run("--output_directory", out, "--gpu_id", "-1", "--water_cube")
     assert r.returncode == 2 and "could not convert" in r.stderr
-    plan = str(tmp_path / "plan.dcm"); open(plan, "wb").write(b"\0" * 132)
+    # DICOM mode: CT series + RT Ion Plan are parsed (include/rtd_dicom.hpp) before the engine is created; two beams are accepted
+    # (the reference throws "Multi-beam calculation not yet supported", main.cu:117-120)
+    import numpy as np
+    import dicom_fixture as dfx
+    ct_dir = str(tmp_path / "ct")
+    dfx.write_ct_series(ct_dir, np.zeros((6, 8, 8), np.int32), (4.0, 4.0, 4.0), (-16.0, -16.0, -12.0))
+    plan = str(tmp_path / "plan.dcm")
+    lay = dict(energy=100.0, fwhm=(10.0, 10.0), x=np.array([-3.0, 0.0, 3.0]), y=np.zeros(3), w=np.ones(3, "f4"))
+    dfx.write_ion_plan(plan, [dict(name="G000", gantry=0.0, iso=(0, 0, 0), vsad=(2000.0, 2000.0), layers=[lay]),
+                              dict(name="G090", gantry=90.0, iso=(0, 0, 0), vsad=(2000.0, 2000.0), layers=[lay])])
     cfg = str(tmp_path / "run.ini")
     open(cfg, "w").write("# run parameters\noutput_directory = \"%s\"\nlut_dir=%s\nct_dir = %s ; series\nrtplan = %s\nbeams = [\"G000\", \"G090\"]\ngpu_id=3\n"
-                         % (out, luts, out, plan))
-    r = run("--config_file", cfg)
-    assert r.returncode == 1 and "Multi-beam calculation not yet supported" in r.stderr       # main.cu:117-120
-    assert 'beams=["G000", "G090"]' in r.stdout and "gpu_id=3" in r.stdout
-    r = run("--config_file", cfg, "--beams", "G000", "--gpu_id", "0")                         # the command line overrides the file
-    assert r.returncode == 3 and "DICOM input" in r.stderr and 'beams=["G000"]' in r.stdout and "gpu_id=0" in r.stdout
+                         % (out, luts, ct_dir, plan))
     import torch
-    if not torch.cuda.is_available():
+    gpu = torch.cuda.is_available()
+    r = run("--config_file", cfg, "--gpu_id", "0")                                            # the command line overrides the file
+    assert 'beams=["G000", "G090"]' in r.stdout and "gpu_id=0" in r.stdout
+    assert "Loading field 1 corresponding to beamname G090" in r.stdout and "3 spots in 1 layer(s) on a 3x1 spot grid" in r.stdout
+    if not gpu:
+        assert r.returncode == 1 and "no CPU fallback" in r.stderr
+    r = run("--config_file", cfg, "--beams", "G045")
+    assert r.returncode == 1 and "no beam named G045" in r.stderr and 'beams=["G045"]' in r.stdout
+    r = run("--config_file", cfg, "--ct_dir", str(tmp_path / "out"))
+    assert r.returncode == 1 and "contains no DICOM Series" in r.stderr
+    if not gpu:
         r = run("--config_file", cfg, "--water_cube", "--water_cube_edge", "16", "--layers", "1", "--gpu_id", "0")
         assert r.returncode == 1 and "no CPU fallback" in r.stderr and "water_cube=true" in r.stdout
 
