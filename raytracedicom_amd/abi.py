@@ -6,6 +6,8 @@ Float3AffineTransform, Float3IdxTransform).
 """
 import ctypes as C
 
+RTD_ABI_VERSION = 2     # include/rtd.h
+
 import numpy as np
 
 RTD_OK = 0

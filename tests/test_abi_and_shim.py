@@ -26,7 +26,9 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 25
     for n in names:
         assert hasattr(lib, n), "librtd_hip.so does not export %s" % n
-    assert engine.lib().rtd_abi_version() == 2
+    assert engine.lib().rtd_abi_version() == abi.RTD_ABI_VERSION == 2
+    import re
+    assert int(re.search(r"#define RTD_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "rtd.h")).read()).group(1)) == abi.RTD_ABI_VERSION
 
 
 def test_struct_sizes_match_header():
@@ -130,6 +132,14 @@ def test_cli_flag_surface_of_the_reference(tmp_path):
     if not gpu:
         r = run("--config_file", cfg, "--water_cube", "--water_cube_edge", "16", "--layers", "1", "--gpu_id", "0")
         assert r.returncode == 1 and "no CPU fallback" in r.stderr and "water_cube=true" in r.stdout
+
+
+def test_graft_entry_build():
+    """__graft_entry__.build() is what the driver runs on the CPU box every round."""
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    importlib.import_module("__graft_entry__").build()
 
 
 def test_product_path_never_imports_the_oracle():
