@@ -110,8 +110,11 @@ class PipelinedBoxReduce:
         if items is None:
             return
         views = []
+        waited = set()
         for work, view, buf in items:
-            work.wait()
+            if id(work) not in waited:
+                work.wait()
+                waited.add(id(work))
             if view is not None:                                     # dst: add the received box
                 view.add_(buf.to(view.device) if buf.device != view.device else buf)
                 views.append(view)
@@ -133,19 +136,30 @@ class PipelinedBoxReduce:
         rank, world = dist.get_rank(), dist.get_world_size()
         valid = [all(b[3 + a] >= b[a] for a in range(3)) for b in boxes]
         items = []
+        ops, meta = [], []
         if rank != self.dst:
             if valid[rank]:
                 packed = self._view(dose_tensor, boxes[rank]).contiguous()
                 if self._staged(dose_tensor):
                     packed = packed.cpu()
-                items.append((dist.isend(packed, self.dst), None, packed))
+                ops.append(dist.P2POp(dist.isend, packed, self.dst))
+                meta.append((None, packed))
         else:
             for r in range(world):
                 if r == self.dst or not valid[r]:
                     continue
                 view = self._view(dose_tensor, boxes[r])
                 buf = torch.empty(view.shape, dtype=dose_tensor.dtype, device="cpu" if self._staged(dose_tensor) else dose_tensor.device)
-                items.append((dist.irecv(buf, src=r), view, buf))
+                ops.append(dist.P2POp(dist.irecv, buf, r))
+                meta.append((view, buf))
+        if ops:
+            # one group: the destination's N-1 receives run concurrently, each over its own link (separate irecv calls would be
+            # serialised on the communication stream)
+            works = dist.batch_isend_irecv(ops)
+            if len(works) == len(ops):
+                items = [(w, v, b) for w, (v, b) in zip(works, meta)]
+            else:                                                    # coalesced into one work object (NCCL)
+                items = [(works[0], v, b) for (v, b) in meta]
         self.pending[id(dose_tensor)] = items
 
     def drain(self):
