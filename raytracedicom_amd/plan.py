@@ -59,6 +59,17 @@ def reduce_dose_bbox(dose_tensor, bbox_min, bbox_max, dist=None, dst=0):
     return dose_tensor
 
 
+class _QueuedAdds:
+    """Adds of received boxes already queued on the side stream: retiring them = making the main stream wait for their event."""
+
+    def __init__(self, event, views, buffers):
+        self.record_event_done, self.views, self.buffers = event, views, buffers
+
+    def wait_on_current_stream(self):
+        import torch
+        torch.cuda.current_stream().wait_event(self.record_event_done)
+
+
 class PipelinedBoxReduce:
     """Sum of the ranks' dose into rank `dst`, sent as point-to-point boxes and left in flight.
 
@@ -84,6 +95,7 @@ class PipelinedBoxReduce:
         self.boxes = None          # [world][6] ints (x0, y0, z0, x1, y1, z1), x1 < x0 = nothing written
         self.pending = {}          # id(dose tensor) -> list of (work, view or None, buffer)
         self.done = {}             # id(dose tensor) -> views the last completed exchange added into (dst), until release() hands them out
+        self.side = None           # (RCCL) stream on which the destination adds the received boxes, concurrently with the next plan's kernels
 
     def _gather_boxes(self, dose_tensor, box_min, box_max):
         import torch
@@ -112,6 +124,10 @@ class PipelinedBoxReduce:
         views = []
         waited = set()
         for work, view, buf in items:
+            if hasattr(work, "record_event_done"):                    # (dst, RCCL) the adds were queued on the side stream at submit
+                work.wait_on_current_stream()
+                views.extend(work.views)
+                continue
             if id(work) not in waited:
                 work.wait()
                 waited.add(id(work))
@@ -160,6 +176,20 @@ class PipelinedBoxReduce:
                 items = [(w, v, b) for w, (v, b) in zip(works, meta)]
             else:                                                    # coalesced into one work object (NCCL)
                 items = [(works[0], v, b) for (v, b) in meta]
+            if rank == self.dst and dose_tensor.is_cuda and dist.get_backend() == "nccl":
+                # RCCL: Work.wait() only makes the CURRENT stream wait, so the adds are queued right now on a side stream: they run
+                # as soon as the boxes have arrived, concurrently with the (compute-bound) kernels of the next plan on the main stream
+                if self.side is None:
+                    self.side = torch.cuda.Stream(device=dose_tensor.device)
+                self.side.wait_stream(torch.cuda.current_stream(dose_tensor.device))      # the volume holds this plan's own field
+                with torch.cuda.stream(self.side):
+                    for w in {id(w): w for w, _, _ in items}.values():
+                        w.wait()
+                    for _, v, b in items:
+                        v.add_(b)
+                    done = torch.cuda.Event()
+                    done.record(self.side)
+                items = [(_QueuedAdds(done, [v for _, v, _ in items], [b for _, _, b in items]), None, None)]
         self.pending[id(dose_tensor)] = items
 
     def drain(self):

@@ -15,6 +15,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _torch_hip_first():
+    """PyTorch carries its own copy of the HIP runtime: in one process it has to initialise BEFORE the engine's (/opt/rocm) copy
+    touches the device, otherwise torch finds "No HIP GPUs" later (bench.py has the same order). Harmless without a GPU."""
+    try:
+        import torch
+        if torch.cuda.device_count() > 0 and torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+
+
 @pytest.fixture(scope="session")
 def orc():
     """The CPU oracle (builds oracle/liboracle.so on first use)."""

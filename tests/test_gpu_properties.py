@@ -158,3 +158,56 @@ def test_clear_dose_resets_exactly_the_written_box(engine, synth):
     fld.destroy()
     eng.device_free(d)
     eng.close()
+
+
+def test_pipelined_exchange_queues_destination_adds_on_a_side_stream():
+    """plan.PipelinedBoxReduce under RCCL (destination rank): the adds of the received boxes are queued on a side stream at submit
+    and retired by an event wait. Exercised on one GPU with a stand-in process group whose receives deliver known boxes."""
+    import torch
+    from raytracedicom_amd import plan
+
+    class Work:
+        def wait(self):
+            return True
+
+    class FakeDist:
+        P2POp = staticmethod(lambda op, tensor, peer: (op, tensor, peer))
+        isend, irecv = "isend", "irecv"
+
+        def get_rank(self): return 0
+        def get_world_size(self): return 3
+        def get_backend(self): return "nccl"
+
+        def all_gather(self, out, mine):
+            boxes = [[2, 3, 4, 9, 8, 7], [0, 0, 0, 5, 5, 5], [6, 6, 6, 5, 5, 5]]     # rank 2 wrote nothing (max < min)
+            for o, b in zip(out, boxes):
+                o.copy_(torch.tensor(b, dtype=o.dtype))
+
+        def batch_isend_irecv(self, ops):
+            for op, tensor, peer in ops:
+                assert op == "irecv" and peer == 1
+                tensor.fill_(float(peer) + 0.5)
+            return [Work()]                                           # coalesced, as RCCL returns it
+
+    dev = torch.device("cuda:0")
+    red = plan.PipelinedBoxReduce(FakeDist(), dst=0, static_boxes=True)
+    vols = [torch.zeros((12, 12, 12), device=dev) for _ in range(2)]
+    for it in range(4):
+        v = vols[it % 2]
+        views = red.release(v)
+        if it >= 2:
+            assert views is not None and len(views) == 1
+            torch.cuda.synchronize()
+            ref = torch.zeros_like(v)
+            ref[4:8, 3:9, 2:10] = 1.0                                  # own field
+            ref[0:6, 0:6, 0:6] += 1.5                                  # + the box received from rank 1
+            assert torch.equal(v, ref)
+            v[4:8, 3:9, 2:10] = 0.0
+            for w in views:
+                w.zero_()
+            assert not bool(v.any())
+        v[4:8, 3:9, 2:10] += 1.0                                       # "compute" this rank's field into its box
+        red.submit(v, (2, 3, 4), (9, 8, 7))
+    red.drain()
+    torch.cuda.synchronize()
+    assert float(vols[1][0, 0, 0]) == 1.5 and float(vols[1][5, 5, 5]) == 2.5 and red.side is not None
