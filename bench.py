@@ -133,15 +133,18 @@ def main():
             for v in views or ():
                 v.zero_()
         f.compute(d.data_ptr())
-        in_flight.append((f, d))
+        ready = torch.cuda.Event() if reducer is not None else None
+        if ready is not None:
+            ready.record(torch.cuda.current_stream())     # the exchange of this plan is ordered behind this plan only
+        in_flight.append((f, d, ready))
 
     def retire():
         """Finish the oldest launched plan: wait for its last kernel, per-stage hipEvent times + bounding box, [N>1: start the
         reduce of the union bounding box into rank 0, left in flight while later plans run]."""
-        f, d = in_flight.pop(0)
+        f, d, ready = in_flight.pop(0)
         t, info = f.finish()
         if reducer is not None:
-            reducer.submit(d, info["dose_box_min"], info["dose_box_max"])
+            reducer.submit(d, info["dose_box_min"], info["dose_box_max"], ready=ready)
         return t, info
 
     def step():

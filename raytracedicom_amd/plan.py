@@ -59,8 +59,14 @@ def reduce_dose_bbox(dose_tensor, bbox_min, bbox_max, dist=None, dst=0):
     return dose_tensor
 
 
+class _NullContext:
+    def __enter__(self): return self
+    def __exit__(self, *a): return False
+
+
 class _QueuedAdds:
-    """Adds of received boxes already queued on the side stream: retiring them = making the main stream wait for their event."""
+    """An exchange whose work (send, or receive + adds) is already queued on the side stream: retiring it = making the main
+    stream wait for its event. Holds the packed / received buffers until then."""
 
     def __init__(self, event, views, buffers):
         self.record_event_done, self.views, self.buffers = event, views, buffers
@@ -144,52 +150,64 @@ class PipelinedBoxReduce:
         views = self.done.pop(id(dose_tensor), None)
         return views if self.dist.get_rank() == self.dst else None
 
-    def submit(self, dose_tensor, box_min, box_max):
+    def submit(self, dose_tensor, box_min, box_max, ready=None):
+        """Start the exchange of the plan that was computed into dose_tensor. `ready` (RCCL only): a torch.cuda.Event recorded on the
+        compute stream right after that plan's kernels were enqueued. With it the exchange is ordered behind THAT plan only; without
+        it, it is ordered behind everything already enqueued on the current stream (which, in a pipelined loop, includes the next
+        plan: RCCL makes its stream wait for the current stream at enqueue time, and the overlap would be lost)."""
         import torch
         dist = self.dist
         assert id(dose_tensor) not in self.pending, "release() the volume before refilling it"
         boxes = self._gather_boxes(dose_tensor, box_min, box_max)
         rank, world = dist.get_rank(), dist.get_world_size()
         valid = [all(b[3 + a] >= b[a] for a in range(3)) for b in boxes]
+        rccl = dose_tensor.is_cuda and dist.get_backend() == "nccl"
         items = []
-        ops, meta = [], []
-        if rank != self.dst:
-            if valid[rank]:
-                packed = self._view(dose_tensor, boxes[rank]).contiguous()
-                if self._staged(dose_tensor):
-                    packed = packed.cpu()
-                ops.append(dist.P2POp(dist.isend, packed, self.dst))
-                meta.append((None, packed))
-        else:
-            for r in range(world):
-                if r == self.dst or not valid[r]:
-                    continue
-                view = self._view(dose_tensor, boxes[r])
-                buf = torch.empty(view.shape, dtype=dose_tensor.dtype, device="cpu" if self._staged(dose_tensor) else dose_tensor.device)
-                ops.append(dist.P2POp(dist.irecv, buf, r))
-                meta.append((view, buf))
-        if ops:
-            # one group: the destination's N-1 receives run concurrently, each over its own link (separate irecv calls would be
-            # serialised on the communication stream)
-            works = dist.batch_isend_irecv(ops)
-            if len(works) == len(ops):
-                items = [(w, v, b) for w, (v, b) in zip(works, meta)]
-            else:                                                    # coalesced into one work object (NCCL)
-                items = [(works[0], v, b) for (v, b) in meta]
-            if rank == self.dst and dose_tensor.is_cuda and dist.get_backend() == "nccl":
-                # RCCL: Work.wait() only makes the CURRENT stream wait, so the adds are queued right now on a side stream: they run
-                # as soon as the boxes have arrived, concurrently with the (compute-bound) kernels of the next plan on the main stream
-                if self.side is None:
-                    self.side = torch.cuda.Stream(device=dose_tensor.device)
-                self.side.wait_stream(torch.cuda.current_stream(dose_tensor.device))      # the volume holds this plan's own field
-                with torch.cuda.stream(self.side):
+        if rccl:
+            # everything of the exchange (packing, send / receive, the destination's adds) is issued with a side stream current
+            if self.side is None:
+                self.side = torch.cuda.Stream(device=dose_tensor.device)
+            if ready is not None:
+                self.side.wait_event(ready)
+            else:
+                self.side.wait_stream(torch.cuda.current_stream(dose_tensor.device))
+        ctx = torch.cuda.stream(self.side) if rccl else _NullContext()
+        with ctx:
+            ops, meta = [], []
+            if rank != self.dst:
+                if valid[rank]:
+                    packed = self._view(dose_tensor, boxes[rank]).contiguous()
+                    if self._staged(dose_tensor):
+                        packed = packed.cpu()
+                    ops.append(dist.P2POp(dist.isend, packed, self.dst))
+                    meta.append((None, packed))
+            else:
+                for r in range(world):
+                    if r == self.dst or not valid[r]:
+                        continue
+                    view = self._view(dose_tensor, boxes[r])
+                    buf = torch.empty(view.shape, dtype=dose_tensor.dtype, device="cpu" if self._staged(dose_tensor) else dose_tensor.device)
+                    ops.append(dist.P2POp(dist.irecv, buf, r))
+                    meta.append((view, buf))
+            if ops:
+                # one group: the destination's N-1 receives run concurrently, each over its own link (separate irecv calls would be
+                # serialised on the communication stream)
+                works = dist.batch_isend_irecv(ops)
+                if len(works) == len(ops):
+                    items = [(w, v, b) for w, (v, b) in zip(works, meta)]
+                else:                                                # coalesced into one work object (RCCL)
+                    items = [(works[0], v, b) for (v, b) in meta]
+                if rccl:
+                    # Work.wait() only makes the CURRENT (= side) stream wait: the destination's adds are queued right now and run
+                    # as soon as the boxes have arrived, concurrently with the (compute-bound) kernels on the main stream
                     for w in {id(w): w for w, _, _ in items}.values():
                         w.wait()
-                    for _, v, b in items:
-                        v.add_(b)
+                    if rank == self.dst:
+                        for _, v, b in items:
+                            v.add_(b)
                     done = torch.cuda.Event()
                     done.record(self.side)
-                items = [(_QueuedAdds(done, [v for _, v, _ in items], [b for _, _, b in items]), None, None)]
+                    items = [(_QueuedAdds(done, [v for _, v, _ in items if v is not None], [b for _, _, b in items]), None, None)]
         self.pending[id(dose_tensor)] = items
 
     def drain(self):

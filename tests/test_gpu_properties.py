@@ -207,7 +207,11 @@ def test_pipelined_exchange_queues_destination_adds_on_a_side_stream():
                 w.zero_()
             assert not bool(v.any())
         v[4:8, 3:9, 2:10] += 1.0                                       # "compute" this rank's field into its box
-        red.submit(v, (2, 3, 4), (9, 8, 7))
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        other = vols[(it + 1) % 2]
+        other.mul_(1.0)                                                # later work on the main stream must not delay the exchange
+        red.submit(v, (2, 3, 4), (9, 8, 7), ready=ready if it % 2 else None)
     red.drain()
     torch.cuda.synchronize()
     assert float(vols[1][0, 0, 0]) == 1.5 and float(vols[1][5, 5, 5]) == 2.5 and red.side is not None
