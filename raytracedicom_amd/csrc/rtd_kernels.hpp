@@ -788,15 +788,16 @@ __global__ void k_ks_plan(FieldState* st, LayerPlan* layers, FieldConst fc, From
 // separable patch  dose_s * e_s[|dy|] * e_s[|dx|],  |dy|,|dx| <= rho_s  (rho_s = batch radius of its 32x8 tile,
 // e_s = erf-difference weights of ITS OWN 1/sigma). A patch is a rank-1 update, so a wave that OWNS a 32x64
 // tile of the padded BEV slice at step k accumulates  D += A * B  with
-//     A[r][s] = dose_s * m_s[r - y_s],   B[s][c] = m_s[c - x_s]      (m_s = mirrored weight table, 0 outside rho_s)
-// on v_mfma_f32_16x16x4_f32 (exact f32 FMA chain at the f32 vector rate; the 8 accumulator tiles have static
+//     A[r][s] = dose_s * m_s[|r - y_s|],   B[s][c] = m_s[|c - x_s|]   (m_s = one-sided weight table of source s, 0 beyond rho_s)
+// on v_mfma_f32_16x16x4_f32 (exact f32 FMA chain at twice the f32 vector FMA rate; the 8 accumulator tiles have static
 // register indices while the operands are data, which a per-source-radius VALU loop cannot have).
-// Work item = (layer group g, step k, output tile): the wave walks the layers l = g, g+G, ... and, per layer,
-// the source rows in reach; a chunk of <= 64 sources of a row gets its weight tables built into the wave's
-// private LDS slice (one source per lane, erfDiffs of kernel_wrapper.cuh:459-467), then every (source quad,
-// 16x16 tile) pair whose bands intersect is one MFMA. No block barrier, no float atomics (the reference's
-// flush, kernel_wrapper.cuh:486), no zero-fill pass (kernel_wrapper.cu:824-827): each partial element is stored
-// once and k_superpose_reduce adds the G partials in fixed order, so the BEV dose is bitwise reproducible.
+// Work item = (output tile, step k, layer group g): the wave walks the layers l = g, g+G, ... and, per layer,
+// the source window in reach in chunks of <= 64 sources; per chunk it computes which of its 8 MFMA tiles every source
+// reaches (own batch radius), builds the weight tables of the chunk into its private LDS slice (one source per lane,
+// the erfDiffs weights of kernel_wrapper.cuh:459-467), then issues one MFMA per (source quad, 16x16 tile) pair in the
+// quad's reach mask. No block barrier, no float atomics (the reference's flush, kernel_wrapper.cuh:486), no zero-fill
+// pass (kernel_wrapper.cu:824-827): each partial element is stored once and k_superpose_reduce adds the G partials
+// in fixed order, so the BEV dose is bitwise reproducible.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kKsSplit = 1;                   // waves per work item (its source chunks are dealt round-robin to them, accumulators
                                               // summed through LDS at the end); measured: 2 = no gain, 4 = slower, so 1 (single-wave blocks)
