@@ -237,3 +237,20 @@ def test_cpp_shim_water_cube_driver(engine, synth, tmp_path):
     assert "water_cube_edge=64" in r2.stdout and "Max:" in r2.stdout
     dose2 = np.fromfile(str(out2 / "dose.dat"), dtype=np.float32)
     assert np.array_equal(dose2, dose.ravel())
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 5, 8, 13, 21, 34])
+def test_seeded_random_scenarios(orc, engine, synth, seed):
+    """Seeded sweep over the knobs that select code paths (layer count vs layer groups, spot grid / ray grid shape, rotation,
+    divergence, step count, sharp and broad spots): every intermediate and the dose against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([48, 64, 96]))
+    ct, _ = scenarios.hetero_phantom(n, seed=int(rng.integers(1, 99)))
+    spots = int(rng.integers(1, 13))
+    pitch = float(rng.choice([2.5, 4.0, 6.0, 9.0]))
+    n_layers = int(rng.choice([1, 2, 7, 14, 15, 17, 23]))
+    deg = float(rng.choice([0.0, 13.0, 90.0, 141.0, 270.0]))
+    dist = (math.inf, math.inf) if rng.random() < 0.4 else (float(rng.uniform(900, 3000)), float(rng.uniform(900, 3000)))
+    steps = int(rng.choice([97, 200, 256, 333]))
+    scn = scenarios.hetero_ct(synth, n=n, spots=spots, pitch=pitch, n_layers=n_layers, angles=[deg], source_dist=dist, steps=steps, ct=ct)
+    _compare_field(orc, engine, scn, scn.beams[0])
