@@ -896,10 +896,13 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
         // (entry Tm is the zero guard: a lane whose row / column is out of the source's reach reads 0) = v_sad_u32 + v_min_u32 +
         // v_lshl_add_u32 per operand. Coordinates carry a bias (64 rows, 128 columns) so that they are unsigned.
         const int ldsBase = (int)(size_t)(__attribute__((address_space(3))) float*)lds;   // LDS byte address of the slice
-        const int laneTab = ldsBase + kq * T * 4;                    // + 16*q*T: the lane's source table (source kq of the quad)
+        int laneTab = ldsBase + kq * T * 4;                          // + 16*q*T: the lane's source table (source kq of the quad)
         const int laneRow = oy0 + li - 32 + 64;                      // + 16*t: output row of the lane in source-row coordinates
         const int laneCol = ox0 + li - kq - 32 - cx0 + 128;          // + 16*t: output column minus the lane's source offset in the quad (window-relative)
-        const int laneD = ldsBase + (CS * T + kq) * 4;               // + 16*q: the lane's dose
+        int laneD = ldsBase + (CS * T + kq) * 4;                     // + 16*q: the lane's dose
+        // (opaque to the optimiser: otherwise it folds the per-visit scalar offset into these per-lane constants as
+        //  (kq + q) * T and re-evaluates that with a quarter-rate v_mul_lo_u32 at every visit)
+        asm volatile("" : "+v"(laneTab), "+v"(laneD));
         // dose and 1/sigma of a chunk are fetched one chunk ahead (one memory round trip, hidden behind the previous chunk)
         const float* __restrict__ iddSlice = bevIdd + sliceOff;
         const float* __restrict__ rsSlice = bevRSigmaEff + sliceOff;
@@ -1004,7 +1007,8 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
                 live &= ~(0xFull << q4);
                 const int qi = __builtin_amdgcn_readlane(qinfo, q4);
                 const int qm = qi & 0xFF, qRow4 = (qi >> 6) & 0x3FFC, qCol4 = (int)(((unsigned)qi >> 18) & 0x3FFC);
-                const int ctr = laneTab + q4 * T * 4;                // byte address of entry 0 of the lane's source table
+                int ctr;                                             // byte address of entry 0 of the lane's source table (one v_add per visit)
+                asm("v_add_u32 %0, %1, %2" : "=v"(ctr) : "s"(q4 * T * 4), "v"(laneTab));
                 const int qRowB = (qRow4 >> 2) + 64, qColB = (qCol4 >> 2) + 128;  // scalar, biased
                 typedef __attribute__((address_space(3))) const float* lptr;
                 const float dl = *(lptr)(size_t)(laneD + 4 * q4);
