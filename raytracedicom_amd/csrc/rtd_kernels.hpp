@@ -908,8 +908,9 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
         const float* __restrict__ rsSlice = bevRSigmaEff + sliceOff;
         float doseN = 0.0f, rsN = 0.0f;
         if (lane < CS && wv * CS + lane < nSrc && sx < cx1) {
-            doseN = iddSlice[(unsigned)(sy * W + sx)];
-            rsN = rsSlice[(unsigned)(sy * W + sx)];
+            const unsigned int off = (unsigned int)(sy * W + sx) * 4u;                 // byte offset within the slice: 32 bits suffice
+            doseN = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(iddSlice) + off);
+            rsN = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rsSlice) + off);
         }
         int sxN = sx, syN = sy;
         for (int s0 = wv * CS; s0 < nSrc; s0 += kKsSplit * CS) {
@@ -920,8 +921,9 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
             if (s0 + kKsSplit * CS < nSrc) {
                 sxN += kKsSplit * CS; while (sxN >= xEnd) { sxN -= nCols; ++syN; }
                 if (lane < CS && s0 + kKsSplit * CS + lane < nSrc && sxN < cx1) {
-                    doseN = iddSlice[(unsigned)(syN * W + sxN)];
-                    rsN = rsSlice[(unsigned)(syN * W + sxN)];
+                    const unsigned int off = (unsigned int)(syN * W + sxN) * 4u;
+                    doseN = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(iddSlice) + off);
+                    rsN = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rsSlice) + off);
                 }
             }
             if (!__any(dose != 0.0f)) continue;                      // chunk carries no dose: contributes exact zeros
