@@ -908,7 +908,7 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
         const float* __restrict__ rsSlice = bevRSigmaEff + sliceOff;
         float doseN = 0.0f, rsN = 0.0f;
         if (lane < CS && wv * CS + lane < nSrc && sx < cx1) {
-            const unsigned int off = (unsigned int)(sy * W + sx) * 4u;                 // byte offset within the slice: 32 bits suffice
+            const unsigned int off = (unsigned int)(__mul24(sy, W) + sx) * 4u;         // byte offset within the slice: 32 bits suffice (W, H <= 4095: 24-bit multiply)
             doseN = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(iddSlice) + off);
             rsN = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rsSlice) + off);
         }
@@ -921,7 +921,7 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
             if (s0 + kKsSplit * CS < nSrc) {
                 sxN += kKsSplit * CS; while (sxN >= xEnd) { sxN -= nCols; ++syN; }
                 if (lane < CS && s0 + kKsSplit * CS + lane < nSrc && sxN < cx1) {
-                    const unsigned int off = (unsigned int)(syN * W + sxN) * 4u;
+                    const unsigned int off = (unsigned int)(__mul24(syN, W) + sxN) * 4u;
                     doseN = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(iddSlice) + off);
                     rsN = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rsSlice) + off);
                 }
@@ -930,7 +930,7 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
             // ---- reach masks: which of the 8 output tiles can each source touch with ITS OWN batch radius ----
             int rhoS = -1, tmask = 0;
             if (dose != 0.0f) {
-                rhoS = effT[((sy >> 3) - ty0) * ntx + ((sx >> 5) - tx0)];
+                rhoS = effT[__mul24((sy >> 3) - ty0, ntx) + ((sx >> 5) - tx0)];
                 if (rhoS < 0) dose = 0.0f;
                 else {
                     const int px = sx + 32 - ox0, py = sy + 32 - oy0;        // source position relative to the owned tile
