@@ -497,7 +497,7 @@ int rtd_field_compute(rtd_handle hh, rtd_field ff, float* dev_dose) {
     {
         const size_t fillLds = (size_t)(2 * h->lut.nSamples + h->lut.nRrl) * sizeof(float);
         const dim3 fillGrid(rayGrid.x * rayGrid.y * fc.L);              // (layer, tile) items; placement is decided in the kernel
-        if (fillLds <= 96 * 1024)
+        if (fillLds <= 48 * 1024)     // + ~9 KiB of static exchange arrays: stays under the 64 KiB default cap of a block's LDS
             launchK((k_fill<true>), fillGrid, blk, fillLds, s, nullptr, ev(3), (const float*)f->dDensity, (const float*)f->dWepl, f->dIdd,
                                   f->dRSigma, (const float*)f->dRayWeights, (const int*)f->dFirstInside, (const int*)f->dFirstOutside,
                                   f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc, (const float*)f->dStepTab, f->dActive, h->numCUs);

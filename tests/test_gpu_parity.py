@@ -254,3 +254,14 @@ def test_seeded_random_scenarios(orc, engine, synth, seed):
     steps = int(rng.choice([97, 200, 256, 333]))
     scn = scenarios.hetero_ct(synth, n=n, spots=spots, pitch=pitch, n_layers=n_layers, angles=[deg], source_dist=dist, steps=steps, ct=ct)
     _compare_field(orc, engine, scn, scn.beams[0])
+
+
+@pytest.mark.parametrize("n_samples,n_hu", [(6144, 3072), (2048, 9000)])
+def test_lookup_tables_too_large_for_lds(orc, engine, n_samples, n_hu):
+    """Tables beyond the LDS staging limits take the global-memory paths: k_fill<false> (two cIDD rows + 1/X0 above 48 KiB) and the
+    tail loop of the tracer's LUT staging (density + SP beyond the 4096 entries held in registers)."""
+    from raytracedicom_amd import luts
+    big = luts.synth_luts(n_energies=40, n_samples=n_samples, n_hu=n_hu)
+    ct, _ = scenarios.hetero_phantom(64)
+    scn = scenarios.hetero_ct(big, n=64, spots=5, pitch=7.0, n_layers=3, angles=[15.0], ct=ct)
+    _compare_field(orc, engine, scn, scn.beams[0])
