@@ -191,11 +191,12 @@ def main():
         elapsed = float(tmax.item())
     ms_per_step = 1000.0 * elapsed / args.steps
 
-    # self-check (untimed): a volume restored by the dirty-box clear of step() must be bit-identical to the same field
-    # computed into a fully zeroed volume (compared before the pending reduce of that step is retired)
+    # self-check (untimed): a volume restored by the dirty-box clear of launch() must be bit-identical to the same field
+    # computed into a fully zeroed volume (compared BEFORE this plan's exchange is submitted: under RCCL the destination's
+    # adds are queued at submit time and may already have run)
     launch()
-    retire()
-    last = doses[(step_no[0] - 1) % len(doses)]
+    f_chk, last, _ = in_flight.pop(0)
+    _, chk_info0 = f_chk.finish()
     ref = torch.zeros_like(last)
     fld.compute(ref.data_ptr())
     fld.finish()
@@ -205,6 +206,7 @@ def main():
         dist.all_reduce(clear_ok, op=dist.ReduceOp.MIN)
     clear_check = bool(int(clear_ok.item()))
     if reducer is not None:
+        reducer.submit(last, chk_info0["dose_box_min"], chk_info0["dose_box_max"])
         reducer.drain()
 
     # N>1 self-check (untimed): the reduced volume on rank 0 must hold the sum of all ranks' fields
