@@ -247,6 +247,8 @@ inline CtVolume readCtSeries(const std::string& dir) {
         const std::vector<double> th = numbers(f0.find(tag(0x0018, 0x0050)));
         if (!th.empty()) dz = th[0];
     }
+    if (nx == 0 || ny == 0 || f0.find(tag(0x7FE0, 0x0010))->value.size() < (size_t)nx * ny * 2)                 // before any allocation sized by the header
+        throw std::runtime_error(f0.path + ": pixel data shorter than rows x columns");
     ct.dim = make_uint3(nx, ny, nz);
     ct.patientPosition = str(f0.find(tag(0x0018, 0x5100)));
     ct.huPlus1000.resize((size_t)nx * ny * nz);
