@@ -512,9 +512,14 @@ int rtd_field_compute(rtd_handle hh, rtd_field ff, float* dev_dose) {
         const int nTX = (fc.bevW + kKsTileX - 1) / kKsTileX, nTY = (fc.bevH + kKsTileY - 1) / kKsTileY;
         const int G = f->ksGroups;
         const int nItems = fc.S * G * nTY * nTX;
-        launchK(k_superpose_mfma, dim3(nItems), dim3(64 * kKsSplit), 0, s, ev(8), ev(7), (const float*)f->dIdd, (const float*)f->dRSigma,
-                              f->dBevPart, (const unsigned char*)f->dTileRad, (const LayerPlan*)f->dLayers, (const FieldState*)f->dState, fc, nTX, nTY, G,
-                              (const int*)f->dActive);
+        // few layers -> few, long work items: deal each item's chunks to 2 or 4 waves (the live items are a fraction of nItems)
+        const int split = nItems >= 48 * 1024 ? 1 : (nItems >= 20 * 1024 ? 2 : 4);
+        auto launchKs = [&](auto kernel) {
+            launchK(kernel, dim3(nItems), dim3(64 * split), 0, s, ev(8), ev(7), (const float*)f->dIdd, (const float*)f->dRSigma,
+                    f->dBevPart, (const unsigned char*)f->dTileRad, (const LayerPlan*)f->dLayers, (const FieldState*)f->dState, fc, nTX, nTY, G,
+                    (const int*)f->dActive);
+        };
+        if (split == 1) launchKs(k_superpose_mfma<1>); else if (split == 2) launchKs(k_superpose_mfma<2>); else launchKs(k_superpose_mfma<4>);
         launchK(k_superpose_reduce, dim3(1024), dim3(256), 0, s, nullptr, ev(5), (const float*)f->dBevPart, f->dBev,
                               (const FieldState*)f->dState, fc, G);
     }

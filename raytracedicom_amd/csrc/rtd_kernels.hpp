@@ -799,8 +799,10 @@ __global__ void k_ks_plan(FieldState* st, LayerPlan* layers, FieldConst fc, From
 // pass (kernel_wrapper.cu:824-827): each partial element is stored once and k_superpose_reduce adds the G partials
 // in fixed order, so the BEV dose is bitwise reproducible.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int kKsSplit = 1;                   // waves per work item (its source chunks are dealt round-robin to them, accumulators
-                                              // summed through LDS at the end); measured: 2 = no gain, 4 = slower, so 1 (single-wave blocks)
+// kKsSplit (template parameter of the kernel) = waves per work item: its source chunks are dealt round-robin to them and the
+// accumulators are summed through LDS at the end, in fixed order. 1 (single-wave blocks) when there are enough items to fill the
+// chip (C3: 2 = no gain, 4 = slower); 2 or 4 for fields with few layers, where the items are too few and too long (C1, one
+// layer: 1872 live items for 7168 wave slots) — chosen on the host from the item count.
 constexpr int kKsWaveLds = 1200;              // floats of LDS per wave (4.7 KiB): tables [CS][T] + doses [CS]; with the reach table
                                               // 5 KiB per block, so LDS admits 31 blocks per CU and the 72 VGPRs 7 waves per SIMD
 constexpr int kKsReachTiles = 80;            // 32x8 source tiles within +-32 of a 64x32 output tile: <= 5 x 13
@@ -808,6 +810,7 @@ constexpr int kKsMaxGroups = 32;              // upper bound of layer groups (= 
 
 __device__ inline int clampI(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+template <int kKsSplit>
 __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float* __restrict__ bevIdd, const float* __restrict__ bevRSigmaEff,
                                                             float* __restrict__ bevPart, const unsigned char* __restrict__ tileRad,
                                                             const LayerPlan* __restrict__ layers, const FieldState* __restrict__ st,
