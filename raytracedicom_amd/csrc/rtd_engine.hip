@@ -29,6 +29,12 @@ namespace {
 
 thread_local std::string g_globalError;
 
+// Lane direction of the tracer and of the dose transfer: the kernels that lay their lanes along the beam / along another dose
+// axis carry a fixed cost (LDS transposition, longer position prefix), so they take over only once the memory axis moves this
+// much faster along their direction than along the plain one. Measured crossovers on the 512^3 field: tracer ~35 degrees
+// (0.130 vs 0.135 ms at 30, 0.166 vs 0.128 at 45), transfer ~38 degrees (0.112 vs 0.125 at 30, 0.142 vs 0.130 at 45).
+constexpr float kTraceAlongRatio = 0.7f, kTransferAxisRatio = 0.8f;
+
 struct rtd_handle_impl {
     int device = 0;
     hipStream_t ownStream = nullptr;
@@ -37,6 +43,7 @@ struct rtd_handle_impl {
     rtd_options opt{};
     int numCUs = 256;             // compute units of the device (grid size of the grid-stride kernels)
     bool scanLdsSet = false;      // dynamic-LDS cap of k_trace_scan raised (once per handle)
+    size_t traceTLds = 0;         // dynamic-LDS cap set for k_trace_sample_t so far
     // LUTs
     bool haveLuts = false;
     std::vector<float> energiesPerU, peakDepths, scaleFacts;
@@ -55,6 +62,8 @@ struct rtd_field_impl {
     FillGeom fillGeom{};
     FromFan rayIdxToDoseIdx{};
     TransferParams transfer0{};
+    int traceMode = 0;              // tracer: 0 lanes across the rays, 1 along the beam (CT x runs along it)
+    int transferMode = 0;           // transfer kernel: lanes of the BEV gathers along dose x (0), y (1) or z (2)
     uint32_t doseDims[3] = {0, 0, 0};
     size_t R = 0;
     // device workspace
@@ -395,9 +404,19 @@ int rtd_field_create(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dims[
     FromFan rayIdxToImIdx; rayIdxToImIdx.fitf = primRayIdxToGantry; rayIdxToImIdx.gtii = toAffine(b->gantry_to_im_idx);
     rayIdxToImIdx.dist.x = b->source_dist[0]; rayIdxToImIdx.dist.y = b->source_dist[1];                        // :657
     f->tracer = makeTracerParams(h->densityScale, h->spScale, (unsigned int)S, rayIdxToImIdx);                 // :766
+    {
+        const float across = std::fabs(f->tracer.coefIdxI.x), along = std::fabs(f->tracer.coefOffset.x * f->tracer.delta.z);
+        f->traceMode = along > kTraceAlongRatio * across ? 1 : 0;
+    }
     f->fillGeom = makeFillGeom(h->rrlScale, rayIdxToImIdx);                                                    // :925
     f->rayIdxToDoseIdx = rayIdxToImIdx; f->rayIdxToDoseIdx.gtii = toAffine(b->gantry_to_dose_idx);             // :1185
     f->transfer0 = makeTransferParams(invertAndShift(f->rayIdxToDoseIdx, v3((float)kMaxSuperpR, (float)kMaxSuperpR, 0.0f)));  // :1213 (z shift on device)
+    {
+        const float ax = std::fabs(f->transfer0.coefIdxI.x), ay = std::fabs(f->transfer0.coefIdxJ.x), az = std::fabs(f->transfer0.inc.x);
+        const int other = ay >= az ? 1 : 2;                           // the axis besides x that moves fastest along BEV x
+        const float ao = std::max(ay, az);
+        f->transferMode = ao > kTransferAxisRatio * ax ? other : 0;
+    }
 
     // per-layer beam-model tables (:792-794, :829-838)
     const int nE = (int)h->energiesPerU.size();
@@ -480,8 +499,20 @@ int rtd_field_compute(rtd_handle hh, rtd_field ff, float* dev_dose) {
                           reinterpret_cast<unsigned int*>(f->dTileRad), f->tileRadWords, f->dActive, (size_t)4 * fc.L * fc.S);
     const size_t lutLds = (size_t)(h->lut.nDensity + h->lut.nSp) * sizeof(float);
     // dIdd doubles as the HU scratch of the tracer (it is written by k_fill only afterwards)
-    k_trace_sample<<<dim3((unsigned)(f->R / 256), (fc.S + kTraceSeg - 1) / kTraceSeg), 256, lutLds, s>>>(
-        h->dCt, (int)h->ctDims[0], (int)h->ctDims[1], (int)h->ctDims[2], h->lut, f->tracer, fc.W, fc.H, f->dDensity, f->dWepl, f->dIdd);
+    const size_t tLds = lutLds + (size_t)3 * kTrRays * kTrPitch * sizeof(float);
+    if (f->traceMode != 0 && tLds <= 144 * 1024) {
+        // the beam runs along the CT x axis: lanes on consecutive steps of one ray (see k_trace_sample_t); 16 rays per block
+        // measured best (4 .. 12 rays: 0.107 - 0.133 ms for the stage, 16: 0.100 ms)
+        if (h->traceTLds < tLds) {
+            RTD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_trace_sample_t), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tLds));
+            h->traceTLds = tLds;
+        }
+        k_trace_sample_t<<<dim3((unsigned)((f->R + kTrRays - 1) / kTrRays)), dim3(64, kTrRays), tLds, s>>>(
+            h->dCt, (int)h->ctDims[0], (int)h->ctDims[1], (int)h->ctDims[2], h->lut, f->tracer, fc.W, fc.H, f->dDensity, f->dWepl, f->dIdd);
+    } else {
+        k_trace_sample<<<dim3((unsigned)(f->R / 256), (fc.S + kTraceSeg - 1) / kTraceSeg), 256, lutLds, s>>>(
+            h->dCt, (int)h->ctDims[0], (int)h->ctDims[1], (int)h->ctDims[2], h->lut, f->tracer, fc.W, fc.H, f->dDensity, f->dWepl, f->dIdd);
+    }
     constexpr size_t scanLds = 2 * kScanChunk * 64 * sizeof(float);   // 128 KiB: above the 64 KiB default cap of dynamic LDS
     if (!h->scanLdsSet) {
         RTD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_trace_scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scanLds));
@@ -528,8 +559,16 @@ int rtd_field_compute(rtd_handle hh, rtd_field ff, float* dev_dose) {
         // grid-stride over the bricks of the device-side box; never more blocks than bricks of the whole volume
         const size_t allBricks = (size_t)((f->doseDims[0] + 31) / 32) * ((f->doseDims[1] + 7) / 8) * ((f->doseDims[2] + zChunk - 1) / zChunk);
         const unsigned tg = (unsigned)std::min<size_t>(allBricks, (size_t)h->numCUs * 8 * 4);
-        launchK(k_transfer, dim3(tg), blk, 0, s, nullptr, f->ev[6], dev_dose, (int)f->doseDims[0], (int)f->doseDims[1],
-                              (int)f->doseDims[2], (const float*)f->dBev, (const FieldState*)f->dState, fc, zChunk);
+        auto launchT = [&](auto kern) {
+            launchK(kern, dim3(tg), blk, 0, s, nullptr, f->ev[6], dev_dose, (int)f->doseDims[0], (int)f->doseDims[1],
+                    (int)f->doseDims[2], (const float*)f->dBev, (const FieldState*)f->dState, fc, zChunk);
+        };
+        // lanes run along the dose axis that moves fastest along BEV x, so that the gathers stay within few BEV rows
+        switch (f->transferMode) {
+            case 0: launchT(k_transfer); break;
+            case 1: launchT(k_transfer_t<1>); break;
+            default: launchT(k_transfer_t<2>); break;
+        }
     }
     RTD_HIP(h, hipGetLastError());
     f->computed = true;

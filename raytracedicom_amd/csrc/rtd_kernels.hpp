@@ -245,6 +245,70 @@ __global__ __launch_bounds__(256) void k_trace_sample(const float* __restrict__ 
     }
 }
 
+// k_trace_sample for beams that run along the CT x axis (gantry near 90 / 270 degrees): there ray-adjacent lanes sample
+// CT voxels one whole slice apart and every load of a wave touches 64 lines in 64 slices (measured 0.22 ms against 0.077 ms
+// at 0 degrees). Here one wave walks ONE ray with its lanes on consecutive steps (lane l takes steps l, l + 64, ...), so a
+// load touches a few consecutive lines; the terms cross an LDS tile [ray][step] and leave with lanes along the rays again
+// (16 rays = 64-byte runs, step-major like the plain kernel). Positions are the same serial `pos += step` sequence.
+// Oblique beams: a mapping with 8 rays x 8 steps per wave (compact in the rotated plane) measured 0.126 ms at every angle,
+// never better than the better of the two lane directions (plain: 0.076 ms at 0 deg, 0.130 at 30, 0.166 at 45; this one: 0.135
+// at 30, 0.128 at 45, 0.100 at 90), so the host just picks between those two.
+constexpr int kTrRays = 16, kTrSteps = 512, kTrPitch = kTrSteps + 4;
+__global__ __launch_bounds__(64 * kTrRays) void k_trace_sample_t(const float* __restrict__ ct, int nx, int ny, int nz, LutView lut,
+                                                                  TracerParams tp, int W, int H, float* __restrict__ bevDensity,
+                                                                  float* __restrict__ spTerm, float* __restrict__ huBuf) {
+    extern __shared__ float sLut[];
+    float* sDensity = sLut;
+    float* sSp = sLut + lut.nDensity;
+    const int nLut = lut.nDensity + lut.nSp;
+    float* tile = sLut + nLut;                                       // [hu, density, sp][kTrRays][kTrPitch]
+    constexpr int nThreads = 64 * kTrRays;
+    const int R = W * H;
+    const int lane = threadIdx.x, wv = threadIdx.y, tid = wv * 64 + lane;
+    const int ray0 = blockIdx.x * kTrRays;
+    // this lane's ray of the block, its first step of a pass, steps per trip, trips per pass
+    const int myRay = wv, myStep0 = lane;
+    constexpr int kStride = 64, kTrips = kTrSteps / kStride;
+    const int ray = min(ray0 + myRay, R - 1);                        // (a last partial block repeats the last ray, stores nothing for it)
+    const int x = ray % W, y = ray / W;
+    const size_t memStep = (size_t)R;
+    for (int i = tid; i < nLut; i += nThreads) sLut[i] = i < lut.nDensity ? lut.density[i] : lut.sp[i - lut.nDensity];
+    Vec3 pos = tp.getStart(x, y);
+    const Vec3 step = tp.getInc(x, y);
+    const float stepLen = tp.stepLen(x, y);
+    for (int i = 0; i < myStep0; ++i) pos = pos + step;              // same float sequence as the serial walk
+    __syncthreads();
+    constexpr int plane = kTrRays * kTrPitch;
+    float* tHu = tile + myRay * kTrPitch + myStep0, *tDe = tHu + plane, *tSp = tDe + plane;
+    const int oRay = tid % kTrRays, oStep = tid / kTrRays;           // write-out: the rays of one step are neighbours (oStep < 64)
+    for (unsigned int base = 0; base < tp.steps; base += kTrSteps) {
+        for (int j = 0; j < kTrips; ++j) {
+            const unsigned int k = base + myStep0 + kStride * j;
+            if (k < tp.steps) {
+                const float huPlus1000 = sample3dBorder(ct, nx, ny, nz, pos.x, pos.y, pos.z);
+                tHu[kStride * j] = huPlus1000;
+                tDe[kStride * j] = sample1dClamp(sDensity, lut.nDensity, huPlus1000 * tp.densityScale);
+                tSp[kStride * j] = stepLen * sample1dClamp(sSp, lut.nSp, huPlus1000 * tp.spScale);
+            }
+            if (k + kStride < tp.steps)                              // on to this lane's next step
+                for (int i = 0; i < kStride; ++i) pos = pos + step;
+        }
+        __syncthreads();
+        const float* oHu = tile + oRay * kTrPitch, *oDe = oHu + plane, *oSp = oDe + plane;
+        if (ray0 + oRay < R)
+            for (int sl = oStep; sl < kTrSteps; sl += 64) {
+                const unsigned int k = base + sl;
+                if (k < tp.steps) {
+                    const size_t idx = (size_t)k * memStep + ray0 + oRay;
+                    huBuf[idx] = oHu[sl];
+                    bevDensity[idx] = oDe[sl];
+                    spTerm[idx] = oSp[sl];
+                }
+            }
+        __syncthreads();
+    }
+}
+
 // The sums are serial per ray (float order of the reference walk, kernel_wrapper.cu:147-186), so only R/64 serial
 // chains of 64 lanes exist: a plain one-wave-per-64-rays walk keeps ~2 MB of loads in flight and is bound by memory
 // latency (measured 57 us for 51 MB). Here a block of kScanWaves waves serves 64 rays: ALL waves stream the next chunk of
@@ -1152,6 +1216,72 @@ __global__ __launch_bounds__(256) void k_transfer(float* __restrict__ dose, int 
 #pragma unroll
             for (int u = 0; u < kZU; ++u) if (tmp[u] > 0.0f) res[u * nxy] += tmp[u];
             res += kZU * nxy;
+        }
+    }
+}
+
+// The same transfer for beams that run along the dose x axis (gantry near 90 / 270 degrees): there x-adjacent voxels lie in
+// different BEV slices and the gathers of k_transfer touch 64 slices per load (measured 0.21 ms against 0.084 ms at 0 degrees).
+// Here the lanes of the gather phase run along the dose axis B (1 = y, 2 = z) that maps to BEV x; the values cross an LDS
+// tile and are added to the dose with lanes along x again. Per voxel the arithmetic is that of k_transfer.
+// (Gathering 8 x 8 patches of the (x, B) plane per wave for oblique beams measured within 3 % of this kernel at 45 degrees.)
+template <int B>
+__global__ __launch_bounds__(256) void k_transfer_t(float* __restrict__ dose, int nx, int ny, int nz,
+                                                     const float* __restrict__ bevDose, const FieldState* __restrict__ st,
+                                                     FieldConst fc, int cChunk) {
+    constexpr int C = B == 1 ? 2 : 1;                                // the axis a thread walks
+    constexpr int kZU = 4;
+    __shared__ float tile[2][kZU][16][17];
+    const int first = st->beamFirstInside;
+    const int slabZ = st->firstCalculatedPassive - first;
+    if (slabZ <= 0) return;
+    const int lo[3] = {st->tboxMin[0], st->tboxMin[1], st->tboxMin[2]};
+    const int hi[3] = {st->tboxMax[0], st->tboxMax[1], st->tboxMax[2]};
+    if (hi[0] < lo[0] || hi[1] < lo[1] || hi[2] < lo[2]) return;
+    const int nbx = (hi[0] - lo[0]) / 16 + 1, nbb = (hi[B] - lo[B]) / 16 + 1, nbc = (hi[C] - lo[C]) / cChunk + 1;
+    const int nBricks = nbx * nbb * nbc;
+    const TransferParams p0 = st->transfer;
+    const float* slab = bevDose + (size_t)first * fc.bevW * fc.bevH;
+    const float exLo = (float)(st->bevLo[0] - 1), exHi = (float)(st->bevHi[0] + 1), eyLo = (float)(st->bevLo[1] - 1), eyHi = (float)(st->bevHi[1] + 1);
+    const size_t nxy = (size_t)nx * ny;
+    const size_t strideB = B == 1 ? (size_t)nx : nxy, strideC = C == 1 ? (size_t)nx : nxy;
+    const int tid = threadIdx.y * 32 + threadIdx.x;
+    const int gB = tid & 15, gX = tid >> 4;                          // gather phase: lanes along B
+    const int aX = tid & 15, aB = tid >> 4;                          // add phase: lanes along x
+    int buf = 0;
+    for (int brick = blockIdx.x; brick < nBricks; brick += gridDim.x) {
+        const int bx = brick % nbx, bb = (brick / nbx) % nbb, bc = brick / (nbx * nbb);
+        const int x0 = lo[0] + 16 * bx, b0 = lo[B] + 16 * bb;
+        const int c0 = lo[C] + bc * cChunk, c1 = min(c0 + cChunk - 1, hi[C]);
+        const int xg = x0 + gX, bg = b0 + gB;
+        const bool gIn = xg <= hi[0] && bg <= hi[B];
+        const int xa = x0 + aX, ba = b0 + aB;
+        const bool aIn = xa <= hi[0] && ba <= hi[B];
+        TransferParams p = p0;
+        if (B == 2) p.init(xg, 0);                                   // y is walked: start is rebuilt per sample below
+        else p.init(xg, bg);
+        float* res = dose + (size_t)c0 * strideC + (size_t)ba * strideB + xa;
+        for (int c = c0; c <= c1; c += kZU) {
+#pragma unroll
+            for (int u = 0; u < kZU; ++u) {
+                float v = 0.0f;
+                if (gIn && c + u <= c1) {
+                    Vec3 pos;
+                    if (B == 2) { TransferParams q = p0; q.init(xg, c + u); pos = q.getFanIdx(bg); }
+                    else pos = p.getFanIdx(c + u);
+                    if (pos.x > exLo && pos.x < exHi && pos.y > eyLo && pos.y < eyHi)
+                        v = sample3dBorder(slab, fc.bevW, fc.bevH, slabZ, pos.x, pos.y, pos.z);
+                }
+                tile[buf][u][gB][gX] = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < kZU; ++u) {
+                const float v = tile[buf][u][aB][aX];
+                if (aIn && v > 0.0f) res[u * strideC] += v;
+            }
+            res += kZU * strideC;
+            buf ^= 1;                                                // the other tile is free: its readers passed the barrier above
         }
     }
 }

@@ -118,16 +118,18 @@ def water_cube_energies(luts, n_layers, e0=118.12, e1=172.51):
     return energies, np.stack([sig, sig], axis=1).astype(np.float32)
 
 
-def _geometry(n, voxel, origin, gantry_deg=0.0):
+def _geometry(n, voxel, origin, gantry_deg=0.0, gantry_rot=None):
     imIdxToWorld = Float3AffineTransform(np.eye(3) * voxel, origin)
     worldToImIdx = imIdxToWorld.inverse()
-    gantryToWorld = Float3AffineTransform(rotation_y(gantry_deg), (0.0, 0.0, 0.0))
+    gantryToWorld = Float3AffineTransform(rotation_y(gantry_deg) if gantry_rot is None else np.asarray(gantry_rot, dtype=float),
+                                          (0.0, 0.0, 0.0))
     return concatFloat3AffineTransform(gantryToWorld, worldToImIdx)     # main.cu:57
 
 
 def make_field(luts, n, voxel, origin, gantry_deg, spots, pitch, n_layers, seed, source_dist=(math.inf, math.inf),
-               steps=512, ray_spacing=(1.0, 1.0), start_z=128.0, step_len=1.0, weight_lo=90.0, weight_span=10.0):
-    gantryToImIdx = _geometry(n, voxel, origin, gantry_deg)
+               steps=512, ray_spacing=(1.0, 1.0), start_z=128.0, step_len=1.0, weight_lo=90.0, weight_span=10.0, gantry_rot=None):
+    """gantry_rot: a 3x3 gantry -> world rotation replacing the rotation about the world Y axis by gantry_deg."""
+    gantryToImIdx = _geometry(n, voxel, origin, gantry_deg, gantry_rot)
     off = -0.5 * (spots - 1) * pitch
     spotIdxToGantry = Float3IdxTransform((pitch, pitch, -step_len), (off, off, start_z))
     rng = np.random.default_rng(seed)
@@ -177,7 +179,7 @@ def hetero_phantom(n, seed=7, noise=20.0):
 
 
 def hetero_ct(luts, n=512, n_fields=1, spots=10, pitch=6.0, n_layers=20, seed=99, source_dist=(math.inf, math.inf),
-              angles=None, steps=512, ct=None):
+              angles=None, steps=512, ct=None, gantry_rot=None):
     """C3 (n=512, 1 field), C4 (n=512, 4 fields at 0/90/180/270), C5 (n=768, 8 fields every 45 deg)."""
     if ct is None:
         ct, voxel = hetero_phantom(n)
@@ -186,7 +188,7 @@ def hetero_ct(luts, n=512, n_fields=1, spots=10, pitch=6.0, n_layers=20, seed=99
     origin = (-128.0, -128.0, -106.0)
     if angles is None:
         angles = [i * 360.0 / n_fields for i in range(n_fields)]
-    beams = [make_field(luts, n, voxel, origin, a, spots, pitch, n_layers, seed + 17 * i, source_dist, steps)
+    beams = [make_field(luts, n, voxel, origin, a, spots, pitch, n_layers, seed + 17 * i, source_dist, steps, gantry_rot=gantry_rot)
              for i, a in enumerate(angles)]
     return Scenario("hetero%d_F%d" % (n, len(beams)), luts, ct, (voxel,) * 3, beams,
                     "heterogeneous CT %d^3, %d field(s), %dx%dx%d spots" % (n, len(beams), spots, spots, n_layers))

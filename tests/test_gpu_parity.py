@@ -121,6 +121,17 @@ def test_heterogeneous_rotated_divergent(orc, engine, synth, deg, dist):
     _compare_field(orc, engine, scn, scn.beams[0])
 
 
+@pytest.mark.parametrize("rot", [((0, 0, 1), (1, 0, 0), (0, 1, 0)), ((0, 0, -1), (0.8, -0.6, 0), (-0.6, -0.8, 0)),
+                                 ((0.8, 0, 0.6), (0, 1, 0), (-0.6, 0, 0.8))])
+def test_beam_axes_other_than_rotation_about_y(orc, engine, synth, rot):
+    """Gantry frames whose BEV x axis runs along dose y (first two: the beam runs along the CT x axis, so the tracer walks one ray
+    per wave and the transfer lays its lanes along y) and an oblique one: the orientation-specific kernels against the oracle."""
+    ct, _ = scenarios.hetero_phantom(96)
+    scn = scenarios.hetero_ct(synth, n=96, spots=5, pitch=7.0, n_layers=3, angles=[0.0], source_dist=(1500.0, 2100.0), steps=300, ct=ct,
+                              gantry_rot=rot)
+    _compare_field(orc, engine, scn, scn.beams[0])
+
+
 def test_wide_field_many_tiles(orc, engine, synth):
     """A field wider than the CT: 448 x 448 rays -> 128 superposition output tiles (> the 64 that get a work-ranked dispatch
     order) and 1568 fill blocks (> 4 per CU: the plain longest-first placement); every intermediate still matches."""
