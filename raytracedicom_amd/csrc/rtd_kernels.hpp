@@ -1196,6 +1196,8 @@ __global__ __launch_bounds__(256) void k_transfer(float* __restrict__ dose, int 
         const int bx = brick % nbx, by = (brick / nbx) % nby, bz = brick / (nbx * nby);
         const int x = bx0 + 32 * bx + threadIdx.x, y = by0 + 8 * by + threadIdx.y;
         const int z0 = bz0 + bz * zChunk, z1 = min(z0 + zChunk - 1, bz1);
+        // (culling whole bricks in the empty corners of an oblique beam's box with an 8-corner test measured slower at every
+        //  angle — 0.095 vs 0.084 ms at 0 degrees, 0.132 vs 0.128 at 45: those bricks already cost one position per voxel only)
         if (x > bx1 || y > by1) continue;                            // (the box lies inside the dose grid)
         TransferParams p = p0;
         p.init(x, y);
