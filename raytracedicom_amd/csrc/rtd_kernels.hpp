@@ -960,12 +960,13 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
         }
         const int xEnd = cx0 + nCols;
         // Per-visit operand addressing: entry u = min(|lane coordinate - source coordinate|, Tm) of the lane's source table
-        // (entry Tm is the zero guard: a lane whose row / column is out of the source's reach reads 0) = v_sad_u32 + v_min_u32 +
-        // v_lshl_add_u32 per operand. Coordinates carry a bias (64 rows, 128 columns) so that they are unsigned.
+        // (entry Tm is the zero guard: a lane whose row / column is out of the source's reach reads 0). With coordinates in
+        // bytes (x 4) the LDS address is min(|lane - source| + table, table + 4 Tm) = v_sad_u32 (with the table base as its
+        // accumulator) + v_min_u32 per operand. Coordinates carry a bias (64 rows, 128 columns) so that they are unsigned.
         const int ldsBase = (int)(size_t)(__attribute__((address_space(3))) float*)lds;   // LDS byte address of the slice
         int laneTab = ldsBase + kq * T * 4;                          // + 16*q*T: the lane's source table (source kq of the quad)
-        const int laneRow = oy0 + li - 32 + 64;                      // + 16*t: output row of the lane in source-row coordinates
-        const int laneCol = ox0 + li - kq - 32 - cx0 + 128;          // + 16*t: output column minus the lane's source offset in the quad (window-relative)
+        const int laneRow4 = 4 * (oy0 + li - 32 + 64);               // output row of the lane in source-row coordinates (tile row t: source - 16 t)
+        const int laneCol4 = 4 * (ox0 + li - kq - 32 - cx0 + 128);   // output column minus the lane's source offset in the quad (window-relative)
         int laneD = ldsBase + (CS * T + kq) * 4;                     // + 16*q: the lane's dose
         // (opaque to the optimiser: otherwise it folds the per-visit scalar offset into these per-lane constants as
         //  (kq + q) * T and re-evaluates that with a quarter-rate v_mul_lo_u32 at every visit)
@@ -1078,23 +1079,24 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
                 const int qm = qi & 0xFF, qRow4 = (qi >> 6) & 0x3FFC, qCol4 = (int)(((unsigned)qi >> 18) & 0x3FFC);
                 int ctr;                                             // byte address of entry 0 of the lane's source table (one v_add per visit)
                 asm("v_add_u32 %0, %1, %2" : "=v"(ctr) : "s"(q4 * T * 4), "v"(laneTab));
-                const int qRowB = (qRow4 >> 2) + 64, qColB = (qCol4 >> 2) + 128;  // scalar, biased
+                const int ctrMax = ctr + 4 * Tm;                     // the zero guard of that table
+                const int qRowB4 = qRow4 + 4 * 64, qColB4 = qCol4 + 4 * 128;    // scalar, biased, in bytes
                 typedef __attribute__((address_space(3))) const float* lptr;
                 const float dl = *(lptr)(size_t)(laneD + 4 * q4);
-                auto entry = [&](int laneCoord, int srcCoord) -> float {
+                auto entry = [&](int laneCoord4, int srcCoord4) -> float {
                     unsigned int u;
-                    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(u) : "v"(laneCoord), "s"(srcCoord));
-                    u = u < (unsigned)Tm ? u : (unsigned)Tm;
-                    return *(lptr)(size_t)(ctr + (int)(u << 2));
+                    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(u) : "v"(laneCoord4), "s"(srcCoord4), "v"(ctr));
+                    u = u < (unsigned)ctrMax ? u : (unsigned)ctrMax;
+                    return *(lptr)(size_t)u;
                 };
                 // operands are fetched only for the tile rows / columns the quad reaches (qm): A = dose * m[|row - y_s|]
                 float a0, a1;                                        // each is read only under the mask bits that set it
-                if (qm & 0x0F) a0 = dl * entry(laneRow, qRowB);
-                if (qm & 0xF0) a1 = dl * entry(laneRow + 16, qRowB);
+                if (qm & 0x0F) a0 = dl * entry(laneRow4, qRowB4);
+                if (qm & 0xF0) a1 = dl * entry(laneRow4, qRowB4 - 64);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     if (qm & (0x11 << t)) {
-                        const float bt = entry(laneCol + 16 * t, qColB);
+                        const float bt = entry(laneCol4, qColB4 - 64 * t);
                         if (qm & (1 << t)) acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bt, acc[0][t], 0, 0, 0);
                         if (qm & (16 << t)) acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bt, acc[1][t], 0, 0, 0);
                     }
