@@ -111,7 +111,13 @@ def main():
     # for its own field's last kernel only): the device does not idle while the host reads back timing and geometry.
     flds = [eng.create_field(beam, scn.dims) for _ in range(2)]
     fld = flds[0]
-    reducer = plan.PipelinedBoxReduce(dist, static_boxes=True) if world > 1 else None   # the fields keep their geometry
+    # N = 2: rank 1 sends its dose box straight to rank 0. N >= 3: point-to-point reduce-scatter + gather (pieces to owner slabs,
+    # complete slabs to rank 0): the links into rank 0 carry (box + union box) / N instead of a whole box each (plan.py).
+    # RTD_BENCH_REDUCE=direct|slab overrides. The fields keep their geometry: the 6-int boxes are exchanged once.
+    reduce_mode = os.environ.get("RTD_BENCH_REDUCE", "slab" if world >= 3 else "direct")
+    reducer = None
+    if world > 1:
+        reducer = (plan.PipelinedSlabReduce if reduce_mode == "slab" else plan.PipelinedBoxReduce)(dist, static_boxes=True)
     torch.cuda.synchronize()
     step_no = [0]
     in_flight = []                      # (field, dose volume) launched, not yet finished
@@ -250,7 +256,12 @@ def main():
                                    "10x10 spots x 20 layers = 2000 spots, 512 tracer steps, 1 mm rays" % (n, world),
                        "ray_grid": info["ray_dims"], "live_steps": info["live_steps"], "max_radius": info["max_radius"],
                        "bbox_voxels": int(np.prod([info["bbox_max"][i] - info["bbox_min"][i] + 1 for i in range(3)])),
-                       "reduce": "each rank sends its packed dose box (rtd_field_info.dose_box) to rank 0 (rccl send/recv over its own xGMI link), rank 0 adds the N-1 boxes; overlapped with the next plan" if world > 1 else "none"},
+                       "reduce": ("none" if world == 1 else
+                                  "point-to-point reduce-scatter + gather over xGMI (rccl send/recv): every rank sends the pieces of its dose box "
+                                  "(rtd_field_info.dose_box) to the ranks that own those slabs, owners add, then send their complete slab "
+                                  "to rank 0; overlapped with the next plan" if reduce_mode == "slab" else
+                                  "each rank sends its packed dose box (rtd_field_info.dose_box) to rank 0 (rccl send/recv over its own xGMI "
+                                  "link), rank 0 adds the N-1 boxes; overlapped with the next plan")},
             "ms_plan": round(ms_per_step, 4),
             "reduce_check_rel_err": reduce_check, "clear_check": clear_check,
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},

@@ -20,6 +20,21 @@ def test_shard_fields():
         plan.shard_fields(4, 2, 2)
 
 
+def test_slab_partition():
+    """Owner slabs of the reduce-scatter form: equal cuts of the union box along the axis that balances the pieces."""
+    # four fields rotating about y (bench N=4): every box has the same y extent -> cut along y, four slabs tiling the union
+    boxes = [[143, 158, 46, 368, 352, 464], [12, 152, 152, 498, 358, 358], [141, 154, 46, 370, 356, 464], [12, 156, 156, 498, 354, 354]]
+    axis, slabs = plan.slab_partition(boxes, 4)
+    assert axis == 1 and [s[1] for s in slabs] == [152, 203, 255, 307] and [s[4] for s in slabs] == [202, 254, 306, 358]
+    assert all(s[0] == 12 and s[3] == 498 and s[2] == 46 and s[5] == 464 for s in slabs)
+    # an empty box takes no part; more ranks than planes along the cut axis leave empty slabs
+    axis, slabs = plan.slab_partition([[0, 0, 0, 1, 1, 1], [5, 5, 5, 4, 4, 4]], 4)
+    assert slabs.count(None) == 2 and [s for s in slabs if s is not None] == [[0, 0, 0, 1, 1, 0], [0, 0, 1, 1, 1, 1]]
+    assert plan.slab_partition([[1, 1, 1, 0, 0, 0]] * 2, 2) == (None, [])
+    assert plan.box_intersection([0, 0, 0, 4, 4, 4], [3, 2, 1, 9, 9, 9]) == [3, 2, 1, 4, 4, 4]
+    assert plan.box_intersection([0, 0, 0, 4, 4, 4], [5, 0, 0, 9, 9, 9]) is None and plan.box_intersection(None, [0] * 6) is None
+
+
 def _worker(rank, world, port, out_path, use_bbox=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -31,7 +46,7 @@ def _worker(rank, world, port, out_path, use_bbox=False):
     oracle.set_threads(2)
     es = luts.synth_luts()
     ct, _ = scenarios.hetero_phantom(64)
-    scn = scenarios.hetero_ct(es, n=64, spots=4, pitch=8.0, n_layers=2, angles=[0.0, 90.0, 200.0][:max(2, world)], ct=ct)
+    scn = scenarios.hetero_ct(es, n=64, spots=4, pitch=8.0, n_layers=2, angles=[0.0, 90.0, 200.0, 300.0][:max(2, world)], ct=ct)
     dose = np.zeros_like(scn.ct)
     t = torch.from_numpy(dose)
 
@@ -43,11 +58,12 @@ def _worker(rank, world, port, out_path, use_bbox=False):
         boxes.append((f.info["bbox_min"], f.info["bbox_max"]))
         f.close()
 
-    if use_bbox == "pipe":
+    if use_bbox in ("pipe", "slab"):
         # four plan iterations on two alternating volumes, reduces left in flight (bench.py's N>1 path). A reused volume is
         # not zeroed as a whole: every rank clears the box its own fields wrote, the destination rank also the boxes it received
         # from the others; a drain() in the middle (bench.py's barrier) must not lose that bookkeeping.
-        red = plan.PipelinedBoxReduce(dist, dst=0)
+        # "slab": the reduce-scatter + gather form (pieces to owner slabs, complete slabs to rank 0): every rank receives dose.
+        red = plan.PipelinedBoxReduce(dist, dst=0) if use_bbox == "pipe" else plan.PipelinedSlabReduce(dist, dst=0)
         vols = [np.zeros_like(scn.ct), np.zeros_like(scn.ct)]
         tens = [torch.from_numpy(v) for v in vols]
         own = [None, None]
@@ -87,7 +103,7 @@ def _worker(rank, world, port, out_path, use_bbox=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("use_bbox,world", [(False, 2), (True, 2), ("pipe", 2), ("pipe", 3)])
+@pytest.mark.parametrize("use_bbox,world", [(False, 2), (True, 2), ("pipe", 2), ("pipe", 3), ("slab", 2), ("slab", 3), ("slab", 4)])
 def test_sharded_plan_equals_sequential(orc, synth, tmp_path, use_bbox, world):
     import torch.multiprocessing as mp
     from raytracedicom_amd import scenarios
@@ -98,7 +114,7 @@ def test_sharded_plan_equals_sequential(orc, synth, tmp_path, use_bbox, world):
     mp.spawn(_worker, args=(world, port, out, use_bbox), nprocs=world, join=True)
     got = np.load(out)
     ct, _ = scenarios.hetero_phantom(64)
-    scn = scenarios.hetero_ct(synth, n=64, spots=4, pitch=8.0, n_layers=2, angles=[0.0, 90.0, 200.0][:max(2, world)], ct=ct)
+    scn = scenarios.hetero_ct(synth, n=64, spots=4, pitch=8.0, n_layers=2, angles=[0.0, 90.0, 200.0, 300.0][:max(2, world)], ct=ct)
     ref = orc.compute(scn)
     assert ref.max() > 0
     np.testing.assert_allclose(got, ref, rtol=1e-6, atol=1e-12 * float(ref.max()))
