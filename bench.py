@@ -62,6 +62,10 @@ def main():
     ap.add_argument("--size", type=int, default=512, help="CT edge in voxels (512 = C3/C4, 768 = C5)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--streams", type=int, default=1,
+                    help="N=1 only, not the default: launch consecutive plans round-robin on this many HIP streams, so the kernels of "
+                         "independent plans overlap (throughput of a multi-field plan on one GPU; per-kernel durations in stage_ms / "
+                         "roofline then include the sharing of the GPU)")
     ap.add_argument("--backend", default="nccl", help="process-group backend; 'gloo' only to rehearse N>1 on a one-GPU box")
     args = ap.parse_args()
 
@@ -105,11 +109,14 @@ def main():
     ct_dev = torch.from_numpy(ct_np).to(dev)
     eng.set_ct_device(ct_dev.data_ptr(), scn.dims)
     # N>1: two alternating dose volumes so that the reduce of plan i (communication stream) overlaps the kernels of plan i+1
-    doses = [torch.zeros((n, n, n), dtype=torch.float32, device=dev) for _ in range(2 if world > 1 else 1)]
+    n_streams = max(1, args.streams)
+    assert n_streams == 1 or world == 1, "--streams is a one-GPU mode"
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else None
+    doses = [torch.zeros((n, n, n), dtype=torch.float32, device=dev) for _ in range(2 if world > 1 else (n_streams + 1 if n_streams > 1 else 1))]
     dose = doses[0]
     # Two field objects of the same beam alternate, so plan i+1 is launched before plan i is finished (rtd_field_finish waits
     # for its own field's last kernel only): the device does not idle while the host reads back timing and geometry.
-    flds = [eng.create_field(beam, scn.dims) for _ in range(2)]
+    flds = [eng.create_field(beam, scn.dims) for _ in range(n_streams + 1)]
     fld = flds[0]
     # N = 2: rank 1 sends its dose box straight to rank 0. N >= 3: point-to-point reduce-scatter + gather (pieces to owner slabs,
     # complete slabs to rank 0): the links into rank 0 carry (box + union box) / N instead of a whole box each (plan.py).
@@ -125,7 +132,9 @@ def main():
     def launch():
         """Launch one plan iteration: fresh dose volume + all kernels of this rank's field (asynchronous)."""
         i = step_no[0]
-        d, f = doses[i % len(doses)], flds[i % 2]
+        d, f = doses[i % len(doses)], flds[i % len(flds)]
+        if streams is not None:
+            eng.set_stream(streams[i % n_streams].cuda_stream)
         first_use = i < len(doses)              # the volume is still the all-zero allocation
         step_no[0] += 1
         views = reducer.release(d) if reducer is not None else None  # the exchange that used this volume two plans ago has completed
@@ -156,7 +165,7 @@ def main():
     def step():
         """One plan iteration in steady state: launch plan i, then finish plan i-1 (pipelined by one)."""
         launch()
-        if len(in_flight) > 1:
+        if len(in_flight) > n_streams:
             return retire()
         return None
 
@@ -254,7 +263,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C3: %d^3 synthetic heterogeneous CT (HU->density/SP LUTs), %d field(s) one per GPU, "
                                    "10x10 spots x 20 layers = 2000 spots, 512 tracer steps, 1 mm rays" % (n, world),
-                       "ray_grid": info["ray_dims"], "live_steps": info["live_steps"], "max_radius": info["max_radius"],
+                       "plans_in_flight_on_streams": n_streams, "ray_grid": info["ray_dims"], "live_steps": info["live_steps"], "max_radius": info["max_radius"],
                        "bbox_voxels": int(np.prod([info["bbox_max"][i] - info["bbox_min"][i] + 1 for i in range(3)])),
                        "reduce": ("none" if world == 1 else
                                   "point-to-point reduce-scatter + gather over xGMI (rccl send/recv): every rank sends the pieces of its dose box "
