@@ -121,13 +121,14 @@ def test_heterogeneous_rotated_divergent(orc, engine, synth, deg, dist):
     _compare_field(orc, engine, scn, scn.beams[0])
 
 
-@pytest.mark.parametrize("rot", [((0, 0, 1), (1, 0, 0), (0, 1, 0)), ((0, 0, -1), (0.8, -0.6, 0), (-0.6, -0.8, 0)),
-                                 ((0.8, 0, 0.6), (0, 1, 0), (-0.6, 0, 0.8))])
-def test_beam_axes_other_than_rotation_about_y(orc, engine, synth, rot):
+@pytest.mark.parametrize("rot,steps", [(((0, 0, 1), (1, 0, 0), (0, 1, 0)), 300), (((0, 0, -1), (0.8, -0.6, 0), (-0.6, -0.8, 0)), 300),
+                                       (((0.8, 0, 0.6), (0, 1, 0), (-0.6, 0, 0.8)), 300),
+                                       (((0, 0, 1), (1, 0, 0), (0, 1, 0)), 600)])      # > 512 steps: two passes of the along-beam tracer
+def test_beam_axes_other_than_rotation_about_y(orc, engine, synth, rot, steps):
     """Gantry frames whose BEV x axis runs along dose y (first two: the beam runs along the CT x axis, so the tracer walks one ray
     per wave and the transfer lays its lanes along y) and an oblique one: the orientation-specific kernels against the oracle."""
     ct, _ = scenarios.hetero_phantom(96)
-    scn = scenarios.hetero_ct(synth, n=96, spots=5, pitch=7.0, n_layers=3, angles=[0.0], source_dist=(1500.0, 2100.0), steps=300, ct=ct,
+    scn = scenarios.hetero_ct(synth, n=96, spots=5, pitch=7.0, n_layers=3, angles=[0.0], source_dist=(1500.0, 2100.0), steps=steps, ct=ct,
                               gantry_rot=rot)
     _compare_field(orc, engine, scn, scn.beams[0])
 
