@@ -1199,7 +1199,10 @@ __global__ __launch_bounds__(256) void k_transfer(float* __restrict__ dose, int 
         const int x = bx0 + 32 * bx + threadIdx.x, y = by0 + 8 * by + threadIdx.y;
         const int z0 = bz0 + bz * zChunk, z1 = min(z0 + zChunk - 1, bz1);
         // (culling whole bricks in the empty corners of an oblique beam's box with an 8-corner test measured slower at every
-        //  angle — 0.095 vs 0.084 ms at 0 degrees, 0.132 vs 0.128 at 45: those bricks already cost one position per voxel only)
+        //  angle — 0.095 vs 0.084 ms at 0 degrees, 0.132 vs 0.128 at 45: those bricks already cost one position per voxel only.
+        //  Also measured slower, parity-green: the 32 loads of the four samples issued before the first use (0.094 ms, 96 VGPRs),
+        //  and the brick's BEV cells staged in LDS so that the gathers hit LDS (0.104 ms; 768^3: 0.257 vs 0.209) — the kernel is
+        //  not bound by the gathers.)
         if (x > bx1 || y > by1) continue;                            // (the box lies inside the dose grid)
         TransferParams p = p0;
         p.init(x, y);
