@@ -35,6 +35,34 @@ def test_slab_partition():
     assert plan.box_intersection([0, 0, 0, 4, 4, 4], [5, 0, 0, 9, 9, 9]) is None and plan.box_intersection(None, [0] * 6) is None
 
 
+def test_union_rects_cover_the_union_exactly():
+    """Phase 2 of the slab reduce sends the union of the field boxes inside a slab as disjoint boxes: exact cover, no overlap."""
+    rng = np.random.default_rng(7)
+    clip = [1, 0, 2, 9, 8, 7]
+    for _ in range(150):
+        boxes = []
+        for _ in range(int(rng.integers(1, 5))):
+            lo = rng.integers(0, 8, 3)
+            hi = lo + rng.integers(0, 6, 3)
+            boxes.append([int(v) for v in lo] + [int(v) for v in hi])
+        want = np.zeros((14, 14, 14), dtype=int)
+        for b in boxes:
+            q = plan.box_intersection(b, clip)
+            if q:
+                want[q[2]:q[5] + 1, q[1]:q[4] + 1, q[0]:q[3] + 1] = 1
+        got = np.zeros_like(want)
+        for q in plan.union_rects(boxes, clip):
+            got[q[2]:q[5] + 1, q[1]:q[4] + 1, q[0]:q[3] + 1] += 1
+        assert (got == want).all()
+    # the four bench fields (cross of two beam directions) inside one slab: a centre block and two arms instead of the full slab
+    boxes = [[143, 158, 46, 368, 352, 464], [12, 152, 152, 498, 358, 358], [141, 154, 46, 370, 356, 464], [12, 156, 156, 498, 354, 354]]
+    _, slabs = plan.slab_partition(boxes, 4)
+    rects = plan.union_rects(boxes, slabs[1])
+    vol = lambda q: (q[3] - q[0] + 1) * (q[4] - q[1] + 1) * (q[5] - q[2] + 1)
+    assert len(rects) == 3 and sum(vol(q) for q in rects) < 0.75 * vol(slabs[1])
+    assert plan.union_rects(boxes, [600, 0, 0, 700, 9, 9]) == []
+
+
 def _worker(rank, world, port, out_path, use_bbox=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
