@@ -965,7 +965,7 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
         // accumulator) + v_min_u32 per operand. Coordinates carry a bias (64 rows, 128 columns) so that they are unsigned.
         const int ldsBase = (int)(size_t)(__attribute__((address_space(3))) float*)lds;   // LDS byte address of the slice
         int laneTab = ldsBase + kq * T * 4;                          // + 16*q*T: the lane's source table (source kq of the quad)
-        const int laneRow4 = 4 * (oy0 + li - 32 + 64);               // output row of the lane in source-row coordinates (tile row t: source - 16 t)
+        const int laneRow4 = 4 * (oy0 + li - 32 - ry0 + 64);         // output row of the lane relative to the window's first source row (tile row t: source - 16 t)
         const int laneCol4 = 4 * (ox0 + li - kq - 32 - cx0 + 128);   // output column minus the lane's source offset in the quad (window-relative)
         int laneD = ldsBase + (CS * T + kq) * 4;                     // + 16*q: the lane's dose
         // (opaque to the optimiser: otherwise it folds the per-visit scalar offset into these per-lane constants as
@@ -1011,8 +1011,10 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
             // bit (4*ty + tx) of a quad's mask = some source of the quad reaches output tile (ty, tx): one MFMA
             tmask |= __builtin_amdgcn_update_dpp(0, tmask, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
             tmask |= __builtin_amdgcn_update_dpp(0, tmask, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
-            unsigned long long live = __ballot(tmask != 0);
-            const int qinfo = tmask | (sy << 8) | ((sx - cx0) << 20);   // one readlane per visit: mask, source row, column in window
+            // (the four lanes of a quad hold the same mask: one ballot bit per quad, bit 4*q)
+            unsigned long long live = __ballot(tmask != 0) & 0x1111111111111111ull;
+            // one readlane per visit: mask | biased source row x 4 (10 bits) | biased column in window x 4 (12 bits): two s_bfe decode them
+            const int qinfo = tmask | ((sy - ry0 + 64) << 10) | ((sx - cx0 + 128) << 20);
             if (!live) continue;                                     // no source of the chunk reaches the tile
             // ---- build: weight table of one source per lane ----
             __builtin_amdgcn_wave_barrier();
@@ -1073,14 +1075,15 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
             // Only quads that reach the tile are visited: their lanes are taken from the wave ballot (scalar bit scan), mask
             // and grid position from the lane that built the quad's first source (one readlane).
             while (live) {
-                const int q4 = __builtin_ctzll(live) & ~3;           // 4*q
-                live &= ~(0xFull << q4);
+                const int q4 = __builtin_ctzll(live);                // 4*q
+                asm("s_bitset0_b64 %0, %1" : "+s"(live) : "s"(q4));     // live &= ~(1 << q4)
                 const int qi = __builtin_amdgcn_readlane(qinfo, q4);
-                const int qm = qi & 0xFF, qRow4 = (qi >> 6) & 0x3FFC, qCol4 = (int)(((unsigned)qi >> 18) & 0x3FFC);
+                const int qm = qi & 0xFF;
                 int ctr;                                             // byte address of entry 0 of the lane's source table (one v_add per visit)
                 asm("v_add_u32 %0, %1, %2" : "=v"(ctr) : "s"(q4 * T * 4), "v"(laneTab));
                 const int ctrMax = ctr + 4 * Tm;                     // the zero guard of that table
-                const int qRowB4 = qRow4 + 4 * 64, qColB4 = qCol4 + 4 * 128;    // scalar, biased, in bytes
+                // scalar, biased, in bytes: bits 8..19 (8, 9 are zero) and bits 18..31 (18, 19 are zero: the row field stays below 256)
+                const int qRowB4 = (qi >> 8) & 0xFFF, qColB4 = (int)((unsigned)qi >> 18);
                 typedef __attribute__((address_space(3))) const float* lptr;
                 const float dl = *(lptr)(size_t)(laneD + 4 * q4);
                 auto entry = [&](int laneCoord4, int srcCoord4) -> float {
