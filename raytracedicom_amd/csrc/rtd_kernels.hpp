@@ -1004,11 +1004,13 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
                     const int px = sx + 32 - ox0, py = sy + 32 - oy0;        // source position relative to the owned tile
                     const int tLo = max((px - rhoS) >> 4, 0), tHi = min((px + rhoS) >> 4, 3);
                     const int xm = tLo <= tHi ? (2 << tHi) - (1 << tLo) : 0; // bits tLo..tHi
-                    if (py + rhoS >= 0 && py - rhoS <= 15) tmask = xm;
-                    if (py + rhoS >= 16 && py - rhoS <= 31) tmask |= xm << 4;
+                    const int rows = ((py + rhoS >= 0 && py - rhoS <= 15) ? 16 : 0) | ((py + rhoS >= 16 && py - rhoS <= 31) ? 32 : 0);
+                    if (xm != 0 && rows != 0) tmask = xm | rows;
                 }
             }
-            // bit (4*ty + tx) of a quad's mask = some source of the quad reaches output tile (ty, tx): one MFMA
+            // A quad's mask: bits 0..3 = tile columns some source of the quad reaches, bit 4 / 5 = upper / lower tile row (the
+            // sources of a quad share row and batch radius, so the rows are common; a pair (row, column) that no source reaches
+            // would only add the tables' zero entries): one MFMA per (row, column) pair, one single-bit scalar test each
             tmask |= __builtin_amdgcn_update_dpp(0, tmask, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
             tmask |= __builtin_amdgcn_update_dpp(0, tmask, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
             // (the four lanes of a quad hold the same mask: one ballot bit per quad, bit 4*q)
@@ -1078,7 +1080,7 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
                 const int q4 = __builtin_ctzll(live);                // 4*q
                 asm("s_bitset0_b64 %0, %1" : "+s"(live) : "s"(q4));     // live &= ~(1 << q4)
                 const int qi = __builtin_amdgcn_readlane(qinfo, q4);
-                const int qm = qi & 0xFF;
+                const int qm = qi;                                   // mask bits 0..5 are tested in place
                 int ctr;                                             // byte address of entry 0 of the lane's source table (one v_add per visit)
                 asm("v_add_u32 %0, %1, %2" : "=v"(ctr) : "s"(q4 * T * 4), "v"(laneTab));
                 const int ctrMax = ctr + 4 * Tm;                     // the zero guard of that table
@@ -1094,14 +1096,18 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
                 };
                 // operands are fetched only for the tile rows / columns the quad reaches (qm): A = dose * m[|row - y_s|]
                 float a0, a1;                                        // each is read only under the mask bits that set it
-                if (qm & 0x0F) a0 = dl * entry(laneRow4, qRowB4);
-                if (qm & 0xF0) a1 = dl * entry(laneRow4, qRowB4 - 64);
+                if (qm & 16) a0 = dl * entry(laneRow4, qRowB4);
+                if (qm & 32) a1 = dl * entry(laneRow4, qRowB4 - 64);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    if (qm & (0x11 << t)) {
+                    if (qm & (1 << t)) {
                         const float bt = entry(laneCol4, qColB4 - 64 * t);
-                        if (qm & (1 << t)) acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bt, acc[0][t], 0, 0, 0);
-                        if (qm & (16 << t)) acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bt, acc[1][t], 0, 0, 0);
+                        // (an opaque copy per column: otherwise the two row tests are hoisted into saved 64-bit conditions,
+                        //  built with vector compares, and every use costs more than the single-bit scalar test it replaces)
+                        int rq = qm;
+                        asm volatile("" : "+s"(rq));
+                        if (rq & 16) acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bt, acc[0][t], 0, 0, 0);
+                        if (rq & 32) acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bt, acc[1][t], 0, 0, 0);
                     }
                 }
             }
