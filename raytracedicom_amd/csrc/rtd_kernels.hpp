@@ -1095,9 +1095,9 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
                     return *(lptr)(size_t)u;
                 };
                 // operands are fetched only for the tile rows / columns the quad reaches (qm): A = dose * m[|row - y_s|]
-                float a0, a1;                                        // each is read only under the mask bits that set it
-                if (qm & 16) a0 = dl * entry(laneRow4, qRowB4);
-                if (qm & 32) a1 = dl * entry(laneRow4, qRowB4 - 64);
+                // (both row operands are always fetched: a row the quad does not reach reads zero entries and is not used;
+                //  two vector + one LDS instruction cost less than the scalar test + branch they replace)
+                const float a0 = dl * entry(laneRow4, qRowB4), a1 = dl * entry(laneRow4, qRowB4 - 64);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     if (qm & (1 << t)) {
