@@ -6,6 +6,7 @@
 // All control scalars (entry step, cut-off steps, tile-radius histograms, work lists, bounding box) stay
 // on the device, so a field is a fixed sequence of launches with no host round trip.
 #pragma once
+#include <type_traits>
 
 #include <hip/hip_runtime.h>
 
@@ -1076,41 +1077,45 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
             // ---- accumulate: one MFMA per (source quad, 16x16 output tile) pair whose bands intersect ----
             // Only quads that reach the tile are visited: their lanes are taken from the wave ballot (scalar bit scan), mask
             // and grid position from the lane that built the quad's first source (one readlane).
-            while (live) {
-                const int q4 = __builtin_ctzll(live);                // 4*q
-                asm("s_bitset0_b64 %0, %1" : "+s"(live) : "s"(q4));     // live &= ~(1 << q4)
-                const int qi = __builtin_amdgcn_readlane(qinfo, q4);
-                const int qm = qi;                                   // mask bits 0..5 are tested in place
-                int ctr;                                             // byte address of entry 0 of the lane's source table (one v_add per visit)
-                asm("v_add_u32 %0, %1, %2" : "=v"(ctr) : "s"(q4 * T * 4), "v"(laneTab));
-                const int ctrMax = ctr + 4 * Tm;                     // the zero guard of that table
-                // scalar, biased, in bytes: bits 8..19 (8, 9 are zero) and bits 18..31 (18, 19 are zero: the row field stays below 256)
-                const int qRowB4 = (qi >> 8) & 0xFFF, qColB4 = (int)((unsigned)qi >> 18);
-                typedef __attribute__((address_space(3))) const float* lptr;
-                const float dl = *(lptr)(size_t)(laneD + 4 * q4);
-                auto entry = [&](int laneCoord4, int srcCoord4) -> float {
-                    unsigned int u;
-                    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(u) : "v"(laneCoord4), "s"(srcCoord4), "v"(ctr));
-                    u = u < (unsigned)ctrMax ? u : (unsigned)ctrMax;
-                    return *(lptr)(size_t)u;
-                };
-                // operands are fetched only for the tile rows / columns the quad reaches (qm): A = dose * m[|row - y_s|]
-                // (both row operands are always fetched: a row the quad does not reach reads zero entries and is not used;
-                //  two vector + one LDS instruction cost less than the scalar test + branch they replace)
-                const float a0 = dl * entry(laneRow4, qRowB4), a1 = dl * entry(laneRow4, qRowB4 - 64);
+            // Three loops, one per row case of the quads (both tile rows, upper only, lower only): inside a loop the rows are
+            // known at compile time, so a visit makes one scalar test per tile column and nothing else — the scalar / branch
+            // path is what limits this loop, not the vector ALUs. (Sums are formed in this fixed order.)
+            auto visits = [&](unsigned long long lv, auto rowsTag) {
+                constexpr int ROWS = decltype(rowsTag)::value;       // bit 0: upper tile row, bit 1: lower tile row
+                while (lv) {
+                    const int q4 = __builtin_ctzll(lv);              // 4*q
+                    asm("s_bitset0_b64 %0, %1" : "+s"(lv) : "s"(q4));   // lv &= ~(1 << q4)
+                    const int qi = __builtin_amdgcn_readlane(qinfo, q4);   // column bits 0..3 are tested in place
+                    int ctr;                                         // byte address of entry 0 of the lane's source table (one v_add per visit)
+                    asm("v_add_u32 %0, %1, %2" : "=v"(ctr) : "s"(q4 * T * 4), "v"(laneTab));
+                    const int ctrMax = ctr + 4 * Tm;                 // the zero guard of that table
+                    // scalar, biased, in bytes: bits 8..19 (8, 9 are zero) and bits 18..31 (18, 19 are zero: the row field stays below 256)
+                    const int qRowB4 = (qi >> 8) & 0xFFF, qColB4 = (int)((unsigned)qi >> 18);
+                    typedef __attribute__((address_space(3))) const float* lptr;
+                    const float dl = *(lptr)(size_t)(laneD + 4 * q4);
+                    auto entry = [&](int laneCoord4, int srcCoord4) -> float {
+                        unsigned int u;
+                        asm("v_sad_u32 %0, %1, %2, %3" : "=v"(u) : "v"(laneCoord4), "s"(srcCoord4), "v"(ctr));
+                        u = u < (unsigned)ctrMax ? u : (unsigned)ctrMax;
+                        return *(lptr)(size_t)u;
+                    };
+                    float a0 = 0.0f, a1 = 0.0f;                      // A = dose * m[|row - y_s|]
+                    if (ROWS & 1) a0 = dl * entry(laneRow4, qRowB4);
+                    if (ROWS & 2) a1 = dl * entry(laneRow4, qRowB4 - 64);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    if (qm & (1 << t)) {
-                        const float bt = entry(laneCol4, qColB4 - 64 * t);
-                        // (an opaque copy per column: otherwise the two row tests are hoisted into saved 64-bit conditions,
-                        //  built with vector compares, and every use costs more than the single-bit scalar test it replaces)
-                        int rq = qm;
-                        asm volatile("" : "+s"(rq));
-                        if (rq & 16) acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bt, acc[0][t], 0, 0, 0);
-                        if (rq & 32) acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bt, acc[1][t], 0, 0, 0);
+                    for (int t = 0; t < 4; ++t) {
+                        if (qi & (1 << t)) {
+                            const float bt = entry(laneCol4, qColB4 - 64 * t);
+                            if (ROWS & 1) acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bt, acc[0][t], 0, 0, 0);
+                            if (ROWS & 2) acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bt, acc[1][t], 0, 0, 0);
+                        }
                     }
                 }
-            }
+            };
+            const int rowBits = tmask & 48;
+            visits(live & __ballot(rowBits == 48), std::integral_constant<int, 3>{});
+            visits(live & __ballot(rowBits == 16), std::integral_constant<int, 1>{});
+            visits(live & __ballot(rowBits == 32), std::integral_constant<int, 2>{});
         }
     }
     // ---- the item's waves add their accumulators in fixed order (wave 0 + wave 1 + ...) through LDS ----
