@@ -882,7 +882,7 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
                                                             FieldConst fc, int nTX, int nTY, int G, const int* __restrict__ active) {
     constexpr int kSlice = kKsWaveLds + kKsReachTiles;
     static_assert(kKsSplit == 1 || kKsSplit * kSlice >= 2048, "the accumulator exchange needs 2048 floats of LDS");
-    __shared__ float ldsAll[kKsSplit * kSlice];
+    __shared__ __attribute__((aligned(16))) float ldsAll[kKsSplit * kSlice];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave of the item (wave-uniform)
     float* lds = ldsAll + wv * kSlice;                             // this wave's private slice
     int* effT = reinterpret_cast<int*>(lds + kKsWaveLds);          // batch radius of every source tile in reach (-1: none)
@@ -945,8 +945,8 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
         const int cx0 = max(max(ox0 - 32 - rho, 0), act[0]), cx1 = min(min(ox0 + 31 + rho + 1, W), -act[2] + 1);
         const int ry0 = max(max(oy0 - 32 - rho, 0), act[1]), ry1 = min(min(oy0 - 1 + rho + 1, H), -act[3] + 1);
         if (cx1 <= cx0 || ry1 <= ry0) continue;
-        const int CS = min(kWave, (kKsWaveLds / (T + 1)) & ~3);      // sources per chunk (whole quads)
-        float* dArr = lds + CS * T;
+        const int CS = min(kWave, (kKsWaveLds / (T + 2)) & ~3);      // sources per chunk (whole quads)
+        float* dArr = lds + CS * T;                                  // per source: (dose, byte offset of the table's zero guard)
         const size_t sliceOff = (size_t)layer * memStep * fc.S + (size_t)k * memStep;
 
         // The window's sources are walked row-major in chunks of CS (rows padded to whole quads), so a chunk may
@@ -968,7 +968,7 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
         int laneTab = ldsBase + kq * T * 4;                          // + 16*q*T: the lane's source table (source kq of the quad)
         const int laneRow4 = 4 * (oy0 + li - 32 - ry0 + 64);         // output row of the lane relative to the window's first source row (tile row t: source - 16 t)
         const int laneCol4 = 4 * (ox0 + li - kq - 32 - cx0 + 128);   // output column minus the lane's source offset in the quad (window-relative)
-        int laneD = ldsBase + (CS * T + kq) * 4;                     // + 16*q: the lane's dose
+        int laneD = ldsBase + (CS * T + 2 * kq) * 4;                 // + 32*q: the lane's (dose, guard offset) pair
         // (opaque to the optimiser: otherwise it folds the per-visit scalar offset into these per-lane constants as
         //  (kq + q) * T and re-evaluates that with a quarter-rate v_mul_lo_u32 at every visit)
         asm volatile("" : "+v"(laneTab), "+v"(laneD));
@@ -1022,7 +1022,12 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
             // ---- build: weight table of one source per lane ----
             __builtin_amdgcn_wave_barrier();
             if (lane < CS) {
-                dArr[lane] = dose;
+                // A source's table is read up to ITS OWN zero guard, entry rhoS + 1 (the lookups clamp to it), so the entries
+                // beyond are never read and need no zeroing: the series below runs unmasked, a dead source (no dose / no
+                // radius) only gets the guard at entry 0.
+                const int guard = rhoS >= 0 ? rhoS + 1 : 0;
+                dArr[2 * lane] = dose;
+                dArr[2 * lane + 1] = __int_as_float(4 * guard);
                 float* m = lds + lane * T;
                 if (rhoS >= 0 && rs <= 0.5f) {
                     // Pixel-integrated Gaussian weights e_i = (1/2)(erf(rs(i+1/2)) - erf(rs(i-1/2))) (kernel_wrapper.cuh:459-467)
@@ -1051,25 +1056,20 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
                         const float s0 = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(c3, w0, c2), w0, c1), w0, c0);
                         const float s1 = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(c3, w1, c2), w1, c1), w1, c0);
                         const float g1 = gq * q, q1 = q * cq;
-                        const float ea = i <= rhoS ? gq * s0 : 0.0f;
-                        const float eb = i + 1 <= rhoS ? g1 * s1 : 0.0f;
+                        const float ea = gq * s0, eb = g1 * s1;
                         gq = g1 * q1; q = q1 * cq;
                         m[i] = ea;
                         if (i + 1 <= Tm) m[i + 1] = eb;
                     }
-                } else {
-                    float erfNew = 0.0f, erfOld = 0.0f;
-                    if (rhoS >= 0) { erfNew = erff(rs * 0.5f); erfOld = -erfNew; }
-                    for (int i = 0; i <= Tm; ++i) {
-                        float e = 0.0f;
-                        if (i <= rhoS) {
-                            e = 0.5f * (erfNew - erfOld);
-                            erfOld = erfNew;
-                            erfNew = erff(rs * ((float)i + 1.5f));
-                        }
-                        m[i] = e;
+                } else if (rhoS >= 0) {
+                    float erfNew = erff(rs * 0.5f), erfOld = -erfNew;
+                    for (int i = 0; i <= rhoS; ++i) {
+                        m[i] = 0.5f * (erfNew - erfOld);
+                        erfOld = erfNew;
+                        erfNew = erff(rs * ((float)i + 1.5f));
                     }
                 }
+                m[guard] = 0.0f;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -1088,11 +1088,13 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
                     const int qi = __builtin_amdgcn_readlane(qinfo, q4);   // column bits 0..3 are tested in place
                     int ctr;                                         // byte address of entry 0 of the lane's source table (one v_add per visit)
                     asm("v_add_u32 %0, %1, %2" : "=v"(ctr) : "s"(q4 * T * 4), "v"(laneTab));
-                    const int ctrMax = ctr + 4 * Tm;                 // the zero guard of that table
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    const f32x2 dg = *(__attribute__((address_space(3))) const f32x2*)(size_t)(laneD + 8 * q4);   // (dose, guard offset)
+                    const int ctrMax = ctr + __float_as_int(dg.y);   // the zero guard of that table
                     // scalar, biased, in bytes: bits 8..19 (8, 9 are zero) and bits 18..31 (18, 19 are zero: the row field stays below 256)
                     const int qRowB4 = (qi >> 8) & 0xFFF, qColB4 = (int)((unsigned)qi >> 18);
                     typedef __attribute__((address_space(3))) const float* lptr;
-                    const float dl = *(lptr)(size_t)(laneD + 4 * q4);
+                    const float dl = dg.x;
                     auto entry = [&](int laneCoord4, int srcCoord4) -> float {
                         unsigned int u;
                         asm("v_sad_u32 %0, %1, %2, %3" : "=v"(u) : "v"(laneCoord4), "s"(srcCoord4), "v"(ctr));
