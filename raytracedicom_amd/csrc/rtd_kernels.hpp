@@ -1027,7 +1027,7 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
                 // radius) only gets the guard at entry 0.
                 const int guard = rhoS >= 0 ? rhoS + 1 : 0;
                 dArr[2 * lane] = dose;
-                dArr[2 * lane + 1] = __int_as_float(4 * guard);
+                dArr[2 * lane + 1] = __int_as_float(ldsBase + (lane * T + guard) * 4);   // LDS byte address of the guard entry
                 float* m = lds + lane * T;
                 if (rhoS >= 0 && rs <= 0.5f) {
                     // Pixel-integrated Gaussian weights e_i = (1/2)(erf(rs(i+1/2)) - erf(rs(i-1/2))) (kernel_wrapper.cuh:459-467)
@@ -1090,7 +1090,7 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
                     asm("v_add_u32 %0, %1, %2" : "=v"(ctr) : "s"(q4 * T * 4), "v"(laneTab));
                     typedef float f32x2 __attribute__((ext_vector_type(2)));
                     const f32x2 dg = *(__attribute__((address_space(3))) const f32x2*)(size_t)(laneD + 8 * q4);   // (dose, guard offset)
-                    const int ctrMax = ctr + __float_as_int(dg.y);   // the zero guard of that table
+                    const int ctrMax = __float_as_int(dg.y);         // the zero guard of that table
                     // scalar, biased, in bytes: bits 8..19 (8, 9 are zero) and bits 18..31 (18, 19 are zero: the row field stays below 256)
                     const int qRowB4 = (qi >> 8) & 0xFFF, qColB4 = (int)((unsigned)qi >> 18);
                     typedef __attribute__((address_space(3))) const float* lptr;
