@@ -945,8 +945,9 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
         const int cx0 = max(max(ox0 - 32 - rho, 0), act[0]), cx1 = min(min(ox0 + 31 + rho + 1, W), -act[2] + 1);
         const int ry0 = max(max(oy0 - 32 - rho, 0), act[1]), ry1 = min(min(oy0 - 1 + rho + 1, H), -act[3] + 1);
         if (cx1 <= cx0 || ry1 <= ry0) continue;
-        const int CS = min(kWave, (kKsWaveLds / (T + 2)) & ~3);      // sources per chunk (whole quads)
-        float* dArr = lds + CS * T;                                  // per source: (dose, byte offset of the table's zero guard)
+        // LDS per source: (dose, address of its table's zero guard) in front of its T table entries, 8-byte aligned
+        const int TS = (T + 3) & ~1;                                 // floats per source
+        const int CS = min(kWave, (kKsWaveLds / TS) & ~3);           // sources per chunk (whole quads)
         const size_t sliceOff = (size_t)layer * memStep * fc.S + (size_t)k * memStep;
 
         // The window's sources are walked row-major in chunks of CS (rows padded to whole quads), so a chunk may
@@ -965,13 +966,12 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
         // bytes (x 4) the LDS address is min(|lane - source| + table, table + 4 Tm) = v_sad_u32 (with the table base as its
         // accumulator) + v_min_u32 per operand. Coordinates carry a bias (64 rows, 128 columns) so that they are unsigned.
         const int ldsBase = (int)(size_t)(__attribute__((address_space(3))) float*)lds;   // LDS byte address of the slice
-        int laneTab = ldsBase + kq * T * 4;                          // + 16*q*T: the lane's source table (source kq of the quad)
+        int laneTab = ldsBase + kq * TS * 4;                         // + 16*q*TS: the lane's source block (source kq of the quad)
         const int laneRow4 = 4 * (oy0 + li - 32 - ry0 + 64);         // output row of the lane relative to the window's first source row (tile row t: source - 16 t)
         const int laneCol4 = 4 * (ox0 + li - kq - 32 - cx0 + 128);   // output column minus the lane's source offset in the quad (window-relative)
-        int laneD = ldsBase + (CS * T + 2 * kq) * 4;                 // + 32*q: the lane's (dose, guard offset) pair
         // (opaque to the optimiser: otherwise it folds the per-visit scalar offset into these per-lane constants as
         //  (kq + q) * T and re-evaluates that with a quarter-rate v_mul_lo_u32 at every visit)
-        asm volatile("" : "+v"(laneTab), "+v"(laneD));
+        asm volatile("" : "+v"(laneTab));
         // dose and 1/sigma of a chunk are fetched one chunk ahead (one memory round trip, hidden behind the previous chunk)
         const float* __restrict__ iddSlice = bevIdd + sliceOff;
         const float* __restrict__ rsSlice = bevRSigmaEff + sliceOff;
@@ -1026,9 +1026,10 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
                 // beyond are never read and need no zeroing: the series below runs unmasked, a dead source (no dose / no
                 // radius) only gets the guard at entry 0.
                 const int guard = rhoS >= 0 ? rhoS + 1 : 0;
-                dArr[2 * lane] = dose;
-                dArr[2 * lane + 1] = __int_as_float(ldsBase + (lane * T + guard) * 4);   // LDS byte address of the guard entry
-                float* m = lds + lane * T;
+                float* sb = lds + lane * TS;
+                sb[0] = dose;
+                sb[1] = __int_as_float(ldsBase + (lane * TS + guard) * 4);   // LDS byte address of the guard entry, less the 8 bytes of this pair
+                float* m = sb + 2;
                 if (rhoS >= 0 && rs <= 0.5f) {
                     // Pixel-integrated Gaussian weights e_i = (1/2)(erf(rs(i+1/2)) - erf(rs(i-1/2))) (kernel_wrapper.cuh:459-467)
                     // evaluated as the Taylor series of the integral around the pixel centre x = rs*i:
@@ -1088,9 +1089,9 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
                     asm("s_bitset0_b64 %0, %1" : "+s"(lv) : "s"(q4));   // lv &= ~(1 << q4)
                     const int qi = __builtin_amdgcn_readlane(qinfo, q4);   // column bits 0..3 are tested in place
                     int ctr;                                         // byte address of entry 0 of the lane's source table (one v_add per visit)
-                    asm("v_add_u32 %0, %1, %2" : "=v"(ctr) : "s"(q4 * T * 4), "v"(laneTab));
+                    asm("v_add_u32 %0, %1, %2" : "=v"(ctr) : "s"(q4 * TS * 4), "v"(laneTab));
                     typedef float f32x2 __attribute__((ext_vector_type(2)));
-                    const f32x2 dg = *(__attribute__((address_space(3))) const f32x2*)(size_t)(laneD + 8 * q4);   // (dose, guard offset)
+                    const f32x2 dg = *(__attribute__((address_space(3))) const f32x2*)(size_t)ctr;   // (dose, guard address) head the source block
                     const int ctrMax = __float_as_int(dg.y);         // the zero guard of that table
                     // scalar, biased, in bytes: bits 8..19 (8, 9 are zero) and bits 18..31 (18, 19 are zero: the row field stays below 256)
                     const int qRowB4 = (qi >> 8) & 0xFFF, qColB4 = (int)((unsigned)qi >> 18);
@@ -1100,7 +1101,7 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
                         unsigned int u;
                         asm("v_sad_u32 %0, %1, %2, %3" : "=v"(u) : "v"(laneCoord4), "s"(srcCoord4), "v"(ctr));
                         u = u < (unsigned)ctrMax ? u : (unsigned)ctrMax;
-                        return *(lptr)(size_t)u;
+                        return *(lptr)(size_t)(u + 8);                // entries follow the pair (immediate offset of the LDS read)
                     };
                     float a0 = 0.0f, a1 = 0.0f;                      // A = dose * m[|row - y_s|]
                     if (ROWS & 1) a0 = dl * entry(laneRow4, qRowB4);
