@@ -868,7 +868,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // accumulators are summed through LDS at the end, in fixed order. 1 (single-wave blocks) when there are enough items to fill the
 // chip (C3: 2 = no gain, 4 = slower); 2 or 4 for fields with few layers, where the items are too few and too long (C1, one
 // layer: 1872 live items for 7168 wave slots) — chosen on the host from the item count.
-constexpr int kKsWaveLds = 1200;              // floats of LDS per wave (4.7 KiB): tables [CS][T] + doses [CS]; with the reach table
+constexpr int kKsWaveLds = 1200;              // floats of LDS per wave (4.7 KiB): CS source blocks (dose, guard address, T entries); with the reach table
                                               // 5 KiB per block, so LDS admits 31 blocks per CU and the 72 VGPRs 7 waves per SIMD
 constexpr int kKsReachTiles = 80;            // 32x8 source tiles within +-32 of a 64x32 output tile: <= 5 x 13
 constexpr int kKsMaxGroups = 32;              // upper bound of layer groups (= partial BEV buffers)
@@ -961,10 +961,11 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
             sy = ry0 + r; sx = cx0 + (i0 - r * nCols);
         }
         const int xEnd = cx0 + nCols;
-        // Per-visit operand addressing: entry u = min(|lane coordinate - source coordinate|, Tm) of the lane's source table
-        // (entry Tm is the zero guard: a lane whose row / column is out of the source's reach reads 0). With coordinates in
-        // bytes (x 4) the LDS address is min(|lane - source| + table, table + 4 Tm) = v_sad_u32 (with the table base as its
-        // accumulator) + v_min_u32 per operand. Coordinates carry a bias (64 rows, 128 columns) so that they are unsigned.
+        // Per-visit operand addressing: entry u = min(|lane coordinate - source coordinate|, guard) of the lane's source table,
+        // guard = the source's own batch radius + 1, where the table holds 0 (a lane whose row / column is out of the source's
+        // reach reads it). With coordinates in bytes (x 4) the LDS address is min(|lane - source| + block, guard address) + 8
+        // = v_sad_u32 (with the block address as its accumulator) + v_min_u32 per operand, the 8 as immediate offset of the read.
+        // Coordinates carry a bias (64 rows, 128 columns) so that they are unsigned.
         const int ldsBase = (int)(size_t)(__attribute__((address_space(3))) float*)lds;   // LDS byte address of the slice
         int laneTab = ldsBase + kq * TS * 4;                         // + 16*q*TS: the lane's source block (source kq of the quad)
         const int laneRow4 = 4 * (oy0 + li - 32 - ry0 + 64);         // output row of the lane relative to the window's first source row (tile row t: source - 16 t)
