@@ -279,8 +279,8 @@ def main():
             "roofline": {"kernel": "rtd::k_superpose_mfma", "bound": "hbm", "achieved": round(ks_gbs, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ks_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "avg_launch_ms": round(ks_ms, 4), "algorithmic_bytes_per_launch": alg["superposition"],
-                         "note": "algorithmic bytes = SURVEY.md 8(d) superposition term 8*(R+P)*sum(A_l); the kernel is instruction-issue bound "
-                                 "(operand fetch around f32 MFMA), not HBM-bound; traffic = (2*FETCH_SIZE+WRITE_SIZE)*1024 from profiles/traffic.json"},
+                         "note": "algorithmic bytes = SURVEY.md 8(d) superposition term 8*(R+P)*sum(A_l); the kernel is bound by vector + f32-matrix "
+                                 "issue cycles (91 % of its SIMD cycles, DESIGN.md section 4), not by HBM; traffic = (2*FETCH_SIZE+WRITE_SIZE)*1024 from profiles/traffic.json"},
         }
         if not args.no_cpu and world == 1:
             from oracle import oracle
