@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RTD_ABI_VERSION 2
+#define RTD_ABI_VERSION 3
 
 typedef enum rtd_status {
     RTD_OK = 0,
@@ -192,6 +192,46 @@ int rtd_field_compute(rtd_handle h, rtd_field f, float* dev_dose);
 int rtd_field_finish(rtd_handle h, rtd_field f, rtd_timing* timing, rtd_field_info* info);
 int rtd_field_clear_dose(rtd_handle h, rtd_field f, float* dev_dose);
 int rtd_field_destroy(rtd_handle h, rtd_field f);
+/* Like rtd_field_destroy, but the device workspace stays with the handle and is taken over by the next rtd_field_create of
+ * the same shape (ray grid, steps, layers, spot map): a plan of similar beams allocates once, where the reference mallocs and
+ * frees ~20 buffers per beam (kernel_wrapper.cu:685-734, 1265-1281). rtd_compute uses it between its beams. */
+int rtd_field_release(rtd_handle h, rtd_field f);
+
+/*
+ * The two halves of rtd_field_compute, and the pieces a multi-GPU plan is made of. The beam loop of the reference
+ * (kernel_wrapper.cu:601) shares nothing between beams but the final `+=` into the dose volume (:92), so fields shard one
+ * per GPU; what then has to cross the xGMI links is NOT the dose: the beam's-eye-view (BEV) dose of a field — the cube the
+ * reference copies into a 3-D texture before primTransfDiv samples it (:1107-1141) — is ~10 MB where the dose box it
+ * turns into is 60-83 MB (512^3 grid). So a field's BEV slab travels, and every GPU runs the transfer of EVERY field into its
+ * own slab of the dose volume:
+ * rtd_field_compute_bev   all kernels up to the BEV dose (:766-1105); asynchronous;
+ * rtd_field_transfer      fan -> dose-grid transfer (primTransfDiv, :69-97) of the field's BEV dose into dev_dose, restricted
+ *                         to the inclusive dose-index box [clip_min, clip_max] (NULL = the whole grid); asynchronous; may be
+ *                         called several times (several volumes / boxes) for one BEV dose;
+ * rtd_field_wait_plan     waits until the field's device-side plan is known (entry / passive steps, BEV rectangle, dose
+ *                         box) — the superposition may still be running — and returns the size of the message below;
+ * rtd_field_export_bev    packs [state record | non-zero block of the BEV dose] into dev_buf (device memory, capacity
+ *                         bytes; rtd_bev_message_bound() is always enough); asynchronous, after rtd_field_compute_bev;
+ * rtd_field_create_remote a field object for a beam computed on ANOTHER GPU: host geometry only, no workspace
+ *                         (needs neither LUTs nor CT on this handle);
+ * rtd_field_attach_bev    the remote field samples the message at dev_buf (device memory of this handle's device, not
+ *                         copied: it must stay valid until the transfers that use it have run); then rtd_field_transfer,
+ *                         rtd_field_clear_dose_box and rtd_field_finish work on it as on a local field.
+ * rtd_field_clear_dose_box zeroes the part of the field's dose box inside [clip_min, clip_max].
+ */
+int rtd_field_compute_bev(rtd_handle h, rtd_field f);
+int rtd_field_transfer(rtd_handle h, rtd_field f, float* dev_dose, const int32_t clip_min[3], const int32_t clip_max[3]);
+int rtd_field_wait_plan(rtd_handle h, rtd_field f, rtd_field_info* info, size_t* packed_bytes);
+size_t rtd_bev_message_bound(rtd_handle h, rtd_field f);
+int rtd_field_export_bev(rtd_handle h, rtd_field f, void* dev_buf, size_t capacity);
+int rtd_field_create_remote(rtd_handle h, const rtd_beam* beam, const uint32_t dose_dims[3], rtd_field* out);
+int rtd_field_attach_bev(rtd_handle h, rtd_field remote_field, const void* dev_buf);
+int rtd_field_clear_dose_box(rtd_handle h, rtd_field f, float* dev_dose, const int32_t clip_min[3], const int32_t clip_max[3]);
+
+/* Page-locks / unlocks a caller-owned host buffer so that rtd_set_ct / rtd_compute copy at full PCIe rate — what
+ * HostPinnedImage3D's constructor and destructor do with cudaHostRegister (host_image_3d.cuh:23-32, 45-48). */
+int rtd_host_register(void* host_ptr, size_t bytes);
+int rtd_host_unregister(void* host_ptr);
 
 /* Device buffers owned by the handle (so a C caller needs no HIP headers). */
 int rtd_device_alloc(rtd_handle h, size_t bytes, void** dev_ptr);
@@ -216,6 +256,43 @@ int rtd_set_stream(rtd_handle h, void* hip_stream);
  */
 int rtd_field_fetch(rtd_handle h, rtd_field f, const char* name, void* host_out, size_t bytes,
                     size_t* bytes_needed);
+
+/*
+ * ---- Multi-GPU plans behind the boundary (SURVEY.md 8(b) "Threading": one handle and one host thread per device) ----
+ *
+ * rtd_plan is the reference-shaped call on several GPUs of one process: the 4-beam cudaWrapperProtons of the C++ shim uses
+ * 4 GPUs. Beams are dealt round-robin to the devices; every device computes the BEV dose of its beams, the packed BEV
+ * slabs (~10 MB each) are pulled by the other devices over xGMI (peer copies), and every device transfers ALL beams, in
+ * beam order, into its own z-slab of the dose volume — uploaded from and downloaded to the caller's host buffer by that
+ * device alone, so the PCIe legs (the bulk of the reference's "total global execution time", kernel_wrapper.cu:410-414,
+ * 1356-1360) run in parallel as well. No dose data crosses between GPUs, and every voxel sees the same `+=` order as on one
+ * GPU: the result equals rtd_compute bit for bit.
+ * device_ids may repeat an id (several handles on one GPU) — used by the tests on one-GPU machines.
+ */
+typedef struct rtd_plan_s* rtd_plan_t;
+
+typedef struct rtd_plan_timing {
+    float total_ms;        /* wall clock of rtd_plan_compute: dose up, all beams, dose down ("Total global execution time
+                              (excluding GPU initialisation)", kernel_wrapper.cu:1356-1360)                              */
+    float upload_ms;       /* slowest device: dose slab host -> device                                                   */
+    float bev_ms;          /* slowest device: its beams up to the BEV dose, slabs exported                               */
+    float exchange_ms;     /* slowest device: pulling the other devices' slabs                                          */
+    float transfer_ms;     /* slowest device: transfers of all beams into its slab                                      */
+    float download_ms;     /* slowest device: dose slab device -> host                                                  */
+    int32_t n_devices;
+    int32_t reserved[3];
+} rtd_plan_timing;
+
+int rtd_plan_create(const int* device_ids, int n_devices, rtd_plan_t* out);
+int rtd_plan_destroy(rtd_plan_t p);
+const char* rtd_plan_last_error(rtd_plan_t p);
+int rtd_plan_set_options(rtd_plan_t p, const rtd_options* opt);
+int rtd_plan_set_luts(rtd_plan_t p, const rtd_luts* luts);                          /* replicated on every device */
+int rtd_plan_load_luts_dir(rtd_plan_t p, const char* dir, int water_cube_test);
+int rtd_plan_set_ct(rtd_plan_t p, const float* hu_plus_1000, const uint32_t dims[3]); /* replicated, uploads in parallel */
+/* per_beam_timing: NULL or n_beams records (filled by the device that computed the beam). */
+int rtd_plan_compute(rtd_plan_t p, const rtd_beam* beams, int n_beams, float* dose_inout, const uint32_t dose_dims[3],
+                     rtd_timing* per_beam_timing, rtd_plan_timing* plan_timing);
 
 #ifdef __cplusplus
 }

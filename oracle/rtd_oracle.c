@@ -20,6 +20,11 @@
  * subtracts it again; the restatement samples at the index-space position directly and uses exact
  * float weights (the hardware quantises weights to 8 fractional bits — not reproduced).
  *
+ * The one transcendental of the sigma recurrence, __powf (kernel_wrapper.cu:282), is restated as rtd_pow_det
+ * (include/rtd_detmath.h): IEEE-only arithmetic shared with the engine so that everything computed from it (the
+ * radius class of every tile, the batch radii) is compared BIT-EXACTLY; its accuracy against a double-precision
+ * pow is pinned by tests/test_oracle_kat.py.
+ *
  * Every function cites the reference lines it follows. Arithmetic is written in the same operand
  * order as the reference and compiled with -ffp-contract=off so that the HIP kernels (written with
  * the same order) can be compared tightly.
@@ -34,6 +39,7 @@
 #endif
 
 #include "../include/rtd.h"
+#include "../include/rtd_detmath.h"   /* rtd_pow_det: the bit-reproducible stand-in for CUDA's __powf, shared with the engine */
 #include "rtd_oracle.h"
 
 /* ------------------------------------------------------------------------------------------ */
@@ -534,7 +540,10 @@ static void stage_fill(const float* bevDensity, const float* bevCumulSp, float* 
                                            cumulSp * params.energyScaleFact, params.energyIdx);
                 float density = bevDensity[idx];
                 if (cumulSp < params.peakDepth) {
-                    float resE = eCoef * powf(params.peakDepth - 0.5f * (cumulSp + cumulSpOld), pInv);
+                    /* __powf (kernel_wrapper.cu:282) is a hardware approximation no other machine reproduces; the
+                     * restatement uses rtd_pow_det (include/rtd_detmath.h, <= 2.7e-7 relative, i.e. tighter than the
+                     * intrinsic): same bits here and on the GPU, so the radius classes below can be compared exactly */
+                    float resE = eCoef * rtd_pow_det(params.peakDepth - 0.5f * (cumulSp + cumulSpOld), pInv);
                     float betaP = resE + 938.3f - 938.3f * 938.3f / (resE + 938.3f);
                     float rRl = density * sample1d_clamp(l->rrl_vector, l->n_rrl_samples, density * params.rRlScale);
                     float thetaSq = eRefSq / (betaP * betaP) * params.stepLength * rRl;
@@ -590,6 +599,8 @@ static void stage_tile_radius(const float* rs, int W, int H, int first, int laye
         ctrs[rad] += 1;
     }
 }
+
+float orc_pow_det(float x, float y) { return rtd_pow_det(x, y); }   /* for the known-answer test of the shared routine */
 
 /* Host batching of radii (kernel_wrapper.cu:966-976): effRad[rad] = template radius of the launch that
  * serves tiles of radius rad (kernel_wrapper.cuh:443-448). Returns layerMaxPrimSuperpR. */

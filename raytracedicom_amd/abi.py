@@ -6,7 +6,7 @@ Float3AffineTransform, Float3IdxTransform).
 """
 import ctypes as C
 
-RTD_ABI_VERSION = 2     # include/rtd.h
+RTD_ABI_VERSION = 3     # include/rtd.h
 
 import numpy as np
 

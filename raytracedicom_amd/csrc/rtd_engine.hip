@@ -35,7 +35,10 @@ thread_local std::string g_globalError;
 // (0.130 vs 0.135 ms at 30, 0.166 vs 0.128 at 45), transfer ~38 degrees (0.112 vs 0.125 at 30, 0.142 vs 0.130 at 45).
 constexpr float kTraceAlongRatio = 0.7f, kTransferAxisRatio = 0.8f;
 
+struct rtd_field_impl;
+
 struct rtd_handle_impl {
+    std::vector<rtd_field_impl*> fieldCache;   // released field objects whose device workspace the next field of the same shape takes over
     int device = 0;
     hipStream_t ownStream = nullptr;
     hipStream_t stream = nullptr;
@@ -56,7 +59,16 @@ struct rtd_handle_impl {
     uint32_t ctDims[3] = {0, 0, 0};
 };
 
+// what the device allocations of a field depend on: a released workspace is reused by a field with the same signature
+struct AllocSig {
+    size_t R = 0, S = 0, L = 0, nSpot = 0, nInterm = 0, G = 0, tileRadWords = 0;
+    bool operator==(const AllocSig& o) const {
+        return R == o.R && S == o.S && L == o.L && nSpot == o.nSpot && nInterm == o.nInterm && G == o.G && tileRadWords == o.tileRadWords;
+    }
+};
+
 struct rtd_field_impl {
+    AllocSig sig;
     FieldConst fc{};
     TracerParams tracer{};
     FillGeom fillGeom{};
@@ -68,7 +80,7 @@ struct rtd_field_impl {
     size_t R = 0;
     // device workspace
     float *dSpotWeights = nullptr, *dConvInterm = nullptr, *dRayWeights = nullptr;
-    float *dDensity = nullptr, *dWepl = nullptr, *dIdd = nullptr, *dRSigma = nullptr, *dBev = nullptr, *dBevPart = nullptr;
+    float *dDensity = nullptr, *dWepl = nullptr, *dRrl = nullptr, *dIdd = nullptr, *dRSigma = nullptr, *dBev = nullptr, *dBevPart = nullptr;
     int *dFirstInside = nullptr, *dFirstOutside = nullptr, *dFirstPassive = nullptr, *dWeplMin = nullptr;
     unsigned char* dTileRad = nullptr;
     size_t tileRadWords = 0;
@@ -80,7 +92,10 @@ struct rtd_field_impl {
     FieldState* dHostState = nullptr;
     std::vector<LayerPlan> hLayers;
     hipEvent_t ev[9] = {};       // 0..6 stage ends, 7 / 8 stop / start of k_superpose_mfma
-    bool computed = false;
+    bool computed = false;       // the BEV dose and the state record of the last rtd_field_compute[_bev] exist (or a slab is attached)
+    bool transferred = false;    // a transfer has been launched since (ev[6] is recorded)
+    bool remote = false;         // geometry only: the BEV slab comes from another GPU (rtd_field_attach_bev)
+    const unsigned char* attached = nullptr;   // remote: the packed message [FieldState | slab]
     int ksGroups = 14;   // layer groups of the superposition (partial BEV buffers); RTD_KS_GROUPS overrides
 };
 
@@ -121,6 +136,18 @@ bool readTokens(const std::string& path, std::vector<double>& out) {
     double v;
     while (f >> v) out.push_back(v);
     return true;
+}
+
+void fillInfo(const rtd_field_impl* f, const FieldState& st, rtd_field_info* info) {
+    std::memset(info, 0, sizeof *info);
+    info->ray_dims[0] = f->fc.W; info->ray_dims[1] = f->fc.H; info->ray_dims[2] = f->fc.L;
+    for (int i = 0; i < 3; ++i) { info->ray_offset[i] = f->fc.rayOffset[i]; info->ray_res[i] = f->fc.rayRes[i]; }
+    info->beam_first_inside = st.beamFirstInside; info->beam_first_outside = st.beamFirstOutside;
+    info->beam_first_guaranteed_passive = st.firstGuaranteedPassive;
+    info->beam_first_calculated_passive = st.firstCalculatedPassive;
+    for (int i = 0; i < 3; ++i) { info->bbox_min[i] = st.bboxMin[i]; info->bbox_max[i] = st.bboxMax[i]; }
+    for (int i = 0; i < 3; ++i) { info->dose_box_min[i] = st.tboxMin[i]; info->dose_box_max[i] = st.tboxMax[i]; }
+    info->live_steps = st.liveSteps; info->max_radius = st.maxRadius;
 }
 
 }  // namespace
@@ -174,6 +201,7 @@ int rtd_destroy(rtd_handle hh) {
     if (!h) return RTD_ERR_INVALID_ARG;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    while (!h->fieldCache.empty()) { rtd_field_impl* c = h->fieldCache.back(); h->fieldCache.pop_back(); rtd_field_destroy(hh, reinterpret_cast<rtd_field>(c)); }
     if (h->dLutBlock) (void)hipFree(h->dLutBlock);
     if (h->dCtOwned) (void)hipFree(h->dCtOwned);
     if (h->ownStream) (void)hipStreamDestroy(h->ownStream);
@@ -209,6 +237,17 @@ int rtd_sync(rtd_handle hh) {
     auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
     if (!h) return RTD_ERR_INVALID_ARG;
     RTD_HIP(h, hipStreamSynchronize(h->stream));
+    return RTD_OK;
+}
+
+int rtd_host_register(void* p, size_t bytes) {   // host_image_3d.cuh:23-32
+    if (!p || !bytes) return RTD_ERR_INVALID_ARG;
+    if (hipHostRegister(p, bytes, hipHostRegisterPortable) != hipSuccess) { (void)hipGetLastError(); g_globalError = "hipHostRegister failed"; return RTD_ERR_HIP; }
+    return RTD_OK;
+}
+int rtd_host_unregister(void* p) {               // host_image_3d.cuh:45-48
+    if (!p) return RTD_ERR_INVALID_ARG;
+    if (hipHostUnregister(p) != hipSuccess) { (void)hipGetLastError(); g_globalError = "hipHostUnregister failed"; return RTD_ERR_HIP; }
     return RTD_OK;
 }
 
@@ -316,6 +355,7 @@ int rtd_load_luts_dir(rtd_handle hh, const char* dir, int water_cube_test) {   /
 int rtd_set_ct_device(rtd_handle hh, const float* dev, const uint32_t dims[3]) {
     auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
     if (!h || !dev || !dims || !dims[0] || !dims[1] || !dims[2]) return RTD_ERR_INVALID_ARG;
+    RTD_HIP(h, hipSetDevice(h->device));
     if (h->dCtOwned) { RTD_HIP(h, hipStreamSynchronize(h->stream)); RTD_HIP(h, hipFree(h->dCtOwned)); h->dCtOwned = nullptr; }
     h->dCt = dev;
     std::memcpy(h->ctDims, dims, sizeof h->ctDims);
@@ -341,7 +381,7 @@ int rtd_field_destroy(rtd_handle hh, rtd_field ff) {
     if (!h || !f) return RTD_ERR_INVALID_ARG;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = { f->dSpotWeights, f->dConvInterm, f->dRayWeights, f->dDensity, f->dWepl, f->dIdd, f->dRSigma, f->dBev, f->dBevPart,
+    void* ptrs[] = { f->dSpotWeights, f->dConvInterm, f->dRayWeights, f->dDensity, f->dWepl, f->dRrl, f->dIdd, f->dRSigma, f->dBev, f->dBevPart,
                      f->dFirstInside, f->dFirstOutside, f->dFirstPassive, f->dWeplMin, f->dTileRad,
                      f->dLayers, f->dState, f->dStepTab, f->dActive };
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -351,12 +391,27 @@ int rtd_field_destroy(rtd_handle hh, rtd_field ff) {
     return RTD_OK;
 }
 
+// Gives the field's device workspace back to the handle: the next rtd_field_create of the same shape (ray grid, steps, layers,
+// spot map) takes it over instead of allocating (the reference mallocs and frees ~20 buffers per beam, :685-734, :1265-1281).
+int rtd_field_release(rtd_handle hh, rtd_field ff) {
+    auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
+    auto* f = reinterpret_cast<rtd_field_impl*>(ff);
+    if (!h || !f) return RTD_ERR_INVALID_ARG;
+    if (f->remote || h->fieldCache.size() >= 4) return rtd_field_destroy(hh, ff);
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);      // its kernels have drained: the next owner uploads with plain copies
+    f->computed = false; f->transferred = false;
+    h->fieldCache.push_back(f);
+    return RTD_OK;
+}
+
 // Host geometry of one beam (kernel_wrapper.cu:612-663, 829-838) + workspace allocation + spot-weight upload (:851).
-int rtd_field_create(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dims[3], rtd_field* out) {
+// remote: geometry only — the field's BEV slab is computed on another GPU and attached (rtd_field_attach_bev).
+static int createField(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dims[3], bool remote, rtd_field* out) {
     auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
     if (!h || !b || !dose_dims || !out) return RTD_ERR_INVALID_ARG;
     *out = nullptr;
-    if (!h->haveLuts || !h->dCt) return fail(h, RTD_ERR_NOT_READY, "rtd_field_create: set LUTs and CT first");
+    if (!remote && (!h->haveLuts || !h->dCt)) return fail(h, RTD_ERR_NOT_READY, "rtd_field_create: set LUTs and CT first");
     if (b->n_layers == 0) return fail(h, RTD_ERR_INVALID_ARG, "Empty list");   // findMax on an empty vector, vector_find.h:24
     if (!b->spot_weights || !b->energies || !b->spot_sigmas || b->spot_nx == 0 || b->spot_ny == 0 || b->tracer_steps == 0)
         return fail(h, RTD_ERR_INVALID_ARG, "rtd_field_create: null or empty beam field");
@@ -385,6 +440,7 @@ int rtd_field_create(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dims[
         return fail(h, RTD_ERR_INVALID_ARG, "rtd_field_create: more than 256 layers or 4096 steps");
 
     auto* f = new rtd_field_impl();
+    f->remote = remote;
     FieldConst& fc = f->fc;
     fc.W = W; fc.H = H; fc.L = L; fc.S = S; fc.bevW = W + 2 * kMaxSuperpR; fc.bevH = H + 2 * kMaxSuperpR;
     fc.tilesX = tilesX; fc.tilesY = tilesY;
@@ -418,6 +474,13 @@ int rtd_field_create(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dims[
         f->transferMode = ao > kTransferAxisRatio * ax ? other : 0;
     }
 
+    if (remote) {
+        hipError_t e = hipEventCreate(&f->ev[0]);
+        if (e == hipSuccess) e = hipEventCreate(&f->ev[6]);
+        if (e != hipSuccess) { h->error = std::string("HIP error: ") + hipGetErrorString(e); rtd_field_destroy(hh, reinterpret_cast<rtd_field>(f)); return RTD_ERR_HIP; }
+        *out = reinterpret_cast<rtd_field>(f);
+        return RTD_OK;
+    }
     // per-layer beam-model tables (:792-794, :829-838)
     const int nE = (int)h->energiesPerU.size();
     float maxEnergy = b->energies[0];
@@ -446,22 +509,39 @@ int rtd_field_create(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dims[
         const size_t cap = (size_t)4 << 30;
         f->ksGroups = (int)std::max<size_t>(1, std::min<size_t>((size_t)f->ksGroups, cap / std::max<size_t>(sliceBytes, 1)));
     }
-    // workspace (the reference's per-beam cudaMallocs, :685-734, :804-808)
+    // workspace (the reference's per-beam cudaMallocs, :685-734, :804-808): taken over from a released field of the same shape
+    // when there is one (rtd_field_release), so a plan of similar beams allocates once
     const size_t R = f->R, P = (size_t)fc.bevW * fc.bevH;
     const size_t nSpot = (size_t)b->spot_nx * b->spot_ny * L;
-    int st = RTD_OK;
-    auto A = [&](auto** p, size_t n) { if (st == RTD_OK) st = devAlloc(h, p, n); };
-    A(&f->dSpotWeights, nSpot); A(&f->dConvInterm, (size_t)W * b->spot_ny * L); A(&f->dRayWeights, R * L);
-    A(&f->dDensity, R * S); A(&f->dWepl, R * S); A(&f->dIdd, R * S * L); A(&f->dRSigma, R * S * L); A(&f->dBev, P * S); A(&f->dBevPart, P * S * f->ksGroups);
-    A(&f->dFirstInside, R); A(&f->dFirstOutside, R); A(&f->dFirstPassive, R * L); A(&f->dWeplMin, (size_t)S);
     f->tileRadWords = ((size_t)L * S * tilesX * tilesY + 3) / 4;      // filled as 32-bit words by k_reset
+    f->sig.R = R; f->sig.S = (size_t)S; f->sig.L = (size_t)L; f->sig.nSpot = nSpot; f->sig.nInterm = (size_t)W * b->spot_ny * L;
+    f->sig.G = (size_t)f->ksGroups; f->sig.tileRadWords = f->tileRadWords;
+    rtd_field_impl* husk = nullptr;
+    for (size_t i = 0; i < h->fieldCache.size(); ++i)
+        if (h->fieldCache[i]->sig == f->sig) { husk = h->fieldCache[i]; h->fieldCache.erase(h->fieldCache.begin() + (long)i); break; }
+    if (husk) {
+        f->dSpotWeights = husk->dSpotWeights; f->dConvInterm = husk->dConvInterm; f->dRayWeights = husk->dRayWeights;
+        f->dDensity = husk->dDensity; f->dWepl = husk->dWepl; f->dRrl = husk->dRrl; f->dIdd = husk->dIdd; f->dRSigma = husk->dRSigma;
+        f->dBev = husk->dBev; f->dBevPart = husk->dBevPart; f->dFirstInside = husk->dFirstInside; f->dFirstOutside = husk->dFirstOutside;
+        f->dFirstPassive = husk->dFirstPassive; f->dWeplMin = husk->dWeplMin; f->dTileRad = husk->dTileRad; f->dLayers = husk->dLayers;
+        f->dState = husk->dState; f->dStepTab = husk->dStepTab; f->dActive = husk->dActive; f->hState = husk->hState; f->dHostState = husk->dHostState;
+        for (int i = 0; i < 9; ++i) f->ev[i] = husk->ev[i];
+        delete husk;
+    }
+    const bool fresh = husk == nullptr;
+    int st = RTD_OK;
+    auto A = [&](auto** p, size_t n) { if (st == RTD_OK && fresh) st = devAlloc(h, p, n); };
+    A(&f->dSpotWeights, nSpot); A(&f->dConvInterm, (size_t)W * b->spot_ny * L); A(&f->dRayWeights, R * L);
+    A(&f->dDensity, R * S); A(&f->dWepl, R * S); A(&f->dRrl, R * S); A(&f->dIdd, R * S * L); A(&f->dRSigma, R * S * L); A(&f->dBev, P * S); A(&f->dBevPart, P * S * f->ksGroups);
+    A(&f->dFirstInside, R); A(&f->dFirstOutside, R); A(&f->dFirstPassive, R * L); A(&f->dWeplMin, (size_t)S);
     A(&f->dTileRad, f->tileRadWords * 4); A(&f->dLayers, (size_t)L); A(&f->dState, (size_t)1); A(&f->dStepTab, (size_t)2 * S); A(&f->dActive, (size_t)4 * L * S);
     if (st != RTD_OK) { rtd_field_destroy(hh, reinterpret_cast<rtd_field>(f)); return st; }
     hipError_t e = hipMemcpy(f->dSpotWeights, b->spot_weights, nSpot * sizeof(float), hipMemcpyHostToDevice);   // :851
     if (e == hipSuccess) e = hipMemcpy(f->dLayers, f->hLayers.data(), (size_t)L * sizeof(LayerPlan), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(f->dState, 0, sizeof(FieldState));
-    if (e == hipSuccess) e = hipHostMalloc((void**)&f->hState, sizeof(FieldState), hipHostMallocMapped);
-    if (e == hipSuccess) { std::memset(f->hState, 0, sizeof(FieldState)); e = hipHostGetDevicePointer((void**)&f->dHostState, f->hState, 0); }
+    if (e == hipSuccess && fresh) e = hipHostMalloc((void**)&f->hState, sizeof(FieldState), hipHostMallocMapped);
+    if (e == hipSuccess && fresh) e = hipHostGetDevicePointer((void**)&f->dHostState, f->hState, 0);
+    if (e == hipSuccess) std::memset(f->hState, 0, sizeof(FieldState));
     {
         std::vector<float> tab(2 * (size_t)S);
         for (int k = 0; k < S; ++k) {
@@ -471,21 +551,28 @@ int rtd_field_create(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dims[
         }
         if (e == hipSuccess) e = hipMemcpy(f->dStepTab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice);
     }
-    for (auto& ev : f->ev) if (e == hipSuccess) e = hipEventCreate(&ev);
+    if (fresh) for (auto& ev : f->ev) if (e == hipSuccess) e = hipEventCreate(&ev);
     if (e != hipSuccess) { h->error = std::string("HIP error: ") + hipGetErrorString(e); rtd_field_destroy(hh, reinterpret_cast<rtd_field>(f)); return RTD_ERR_HIP; }
-    e = hipMemset(f->dBev, 0, P * (size_t)S * sizeof(float));   // slices outside [entry, passive) are never written: keep them zero
+    // (the transfer reads the slices [entry, passive) only, and the superposition's reduce writes every pixel of those: slices
+    //  outside hold stale values that nothing samples; a fresh buffer is cleared once so that a fetch of "bev" reads zeros there)
+    if (fresh) e = hipMemset(f->dBev, 0, P * (size_t)S * sizeof(float));
     if (e != hipSuccess) { h->error = std::string("HIP error: ") + hipGetErrorString(e); rtd_field_destroy(hh, reinterpret_cast<rtd_field>(f)); return RTD_ERR_HIP; }
     *out = reinterpret_cast<rtd_field>(f);
     return RTD_OK;
 }
 
-// The beam loop body as launches only (kernel_wrapper.cu:766-1218). Asynchronous on the handle's stream.
+int rtd_field_create(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dims[3], rtd_field* out) { return createField(hh, b, dose_dims, false, out); }
+int rtd_field_create_remote(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dims[3], rtd_field* out) { return createField(hh, b, dose_dims, true, out); }
 
-int rtd_field_compute(rtd_handle hh, rtd_field ff, float* dev_dose) {
+// The beam loop body as launches only (kernel_wrapper.cu:766-1218). Asynchronous on the handle's stream.
+// Part 1: everything up to the beam's-eye-view dose (:766-1105).
+int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
     auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
     auto* f = reinterpret_cast<rtd_field_impl*>(ff);
-    if (!h || !f || !dev_dose) return RTD_ERR_INVALID_ARG;
+    if (!h || !f) return RTD_ERR_INVALID_ARG;
+    if (f->remote) return fail(h, RTD_ERR_INVALID_ARG, "rtd_field_compute_bev: a remote field has no workspace (attach a slab instead)");
     if (!h->dCt || !h->haveLuts) return fail(h, RTD_ERR_NOT_READY, "rtd_field_compute: set LUTs and CT first");
+    RTD_HIP(h, hipSetDevice(h->device));   // one host thread may drive handles on several devices
     const FieldConst& fc = f->fc;
     hipStream_t s = h->stream;
     const bool timing = h->opt.fine_grained_timing != 0;
@@ -508,10 +595,10 @@ int rtd_field_compute(rtd_handle hh, rtd_field ff, float* dev_dose) {
             h->traceTLds = tLds;
         }
         k_trace_sample_t<<<dim3((unsigned)((f->R + kTrRays - 1) / kTrRays)), dim3(64, kTrRays), tLds, s>>>(
-            h->dCt, (int)h->ctDims[0], (int)h->ctDims[1], (int)h->ctDims[2], h->lut, f->tracer, fc.W, fc.H, f->dDensity, f->dWepl, f->dIdd);
+            h->dCt, (int)h->ctDims[0], (int)h->ctDims[1], (int)h->ctDims[2], h->lut, f->tracer, fc.W, fc.H, f->dDensity, f->dWepl, f->dIdd, f->dRrl, h->rrlScale);
     } else {
         k_trace_sample<<<dim3((unsigned)(f->R / 256), (fc.S + kTraceSeg - 1) / kTraceSeg), 256, lutLds, s>>>(
-            h->dCt, (int)h->ctDims[0], (int)h->ctDims[1], (int)h->ctDims[2], h->lut, f->tracer, fc.W, fc.H, f->dDensity, f->dWepl, f->dIdd);
+            h->dCt, (int)h->ctDims[0], (int)h->ctDims[1], (int)h->ctDims[2], h->lut, f->tracer, fc.W, fc.H, f->dDensity, f->dWepl, f->dIdd, f->dRrl, h->rrlScale);
     }
     constexpr size_t scanLds = 2 * kScanChunk * 64 * sizeof(float);   // 128 KiB: above the 64 KiB default cap of dynamic LDS
     if (!h->scanLdsSet) {
@@ -526,18 +613,19 @@ int rtd_field_compute(rtd_handle hh, rtd_field ff, float* dev_dose) {
     launchK(k_conv_y, dim3(fc.W / 32, fc.H / 8, fc.L), blk, 0, s, nullptr, ev(2), (const float*)f->dConvInterm, f->dRayWeights,
                           (const LayerPlan*)f->dLayers, (const FieldState*)f->dState, fc);
     {
-        const size_t fillLds = (size_t)(2 * h->lut.nSamples + h->lut.nRrl) * sizeof(float);
-        const dim3 fillGrid(rayGrid.x * rayGrid.y * fc.L);              // (layer, tile) items; placement is decided in the kernel
-        if (fillLds <= 48 * 1024)     // + ~9 KiB of static exchange arrays: stays under the 64 KiB default cap of a block's LDS
-            launchK((k_fill<true>), fillGrid, blk, fillLds, s, nullptr, ev(3), (const float*)f->dDensity, (const float*)f->dWepl, f->dIdd,
+        const size_t fillLds = (size_t)(2 * h->lut.nSamples) * sizeof(float);   // the layer's two cumulative-IDD rows
+        const dim3 fillGrid(2 * rayGrid.x * rayGrid.y * fc.L);          // (layer, tile, role) items: sigma walk and dose walk of every tile; placement is decided in the kernel
+        const dim3 fillBlk = blk;
+        if (fillLds <= 40 * 1024)     // + ~17 KiB of static exchange arrays: stays under the 64 KiB default cap of a block's LDS
+            launchK((k_fill<true>), fillGrid, fillBlk, fillLds, s, nullptr, ev(3), (const float*)f->dDensity, (const float*)f->dWepl, (const float*)f->dRrl, f->dIdd,
                                   f->dRSigma, (const float*)f->dRayWeights, (const int*)f->dFirstInside, (const int*)f->dFirstOutside,
                                   f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc, (const float*)f->dStepTab, f->dActive, h->numCUs);
         else
-            launchK((k_fill<false>), fillGrid, blk, 0, s, nullptr, ev(3), (const float*)f->dDensity, (const float*)f->dWepl, f->dIdd,
+            launchK((k_fill<false>), fillGrid, fillBlk, 0, s, nullptr, ev(3), (const float*)f->dDensity, (const float*)f->dWepl, (const float*)f->dRrl, f->dIdd,
                                   f->dRSigma, (const float*)f->dRayWeights, (const int*)f->dFirstInside, (const int*)f->dFirstOutside,
                                   f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc, (const float*)f->dStepTab, f->dActive, h->numCUs);
     }
-    launchK(k_ks_plan, dim3(1), dim3(64), 0, s, nullptr, ev(4), f->dState, f->dLayers, fc, f->rayIdxToDoseIdx, f->transfer0,
+    launchK(k_ks_plan, dim3(1), dim3(64), 0, s, nullptr, f->ev[4], f->dState, f->dLayers, fc, f->rayIdxToDoseIdx, f->transfer0,
                           (int)f->doseDims[0], (int)f->doseDims[1], (int)f->doseDims[2], f->ksGroups, f->dHostState);
     {
         const int nTX = (fc.bevW + kKsTileX - 1) / kKsTileX, nTY = (fc.bevH + kKsTileY - 1) / kKsTileY;
@@ -551,17 +639,43 @@ int rtd_field_compute(rtd_handle hh, rtd_field ff, float* dev_dose) {
                     (const int*)f->dActive);
         };
         if (split == 1) launchKs(k_superpose_mfma<1>); else if (split == 2) launchKs(k_superpose_mfma<2>); else launchKs(k_superpose_mfma<4>);
-        launchK(k_superpose_reduce, dim3(1024), dim3(256), 0, s, nullptr, ev(5), (const float*)f->dBevPart, f->dBev,
+        launchK(k_superpose_reduce, dim3(1024), dim3(256), 0, s, nullptr, f->ev[5], (const float*)f->dBevPart, f->dBev,
                               (const FieldState*)f->dState, fc, G);
     }
+    RTD_HIP(h, hipGetLastError());
+    f->computed = true;
+    f->transferred = false;
+    return RTD_OK;
+}
+
+static ClipBox makeClip(const int32_t* lo, const int32_t* hi) {
+    ClipBox c;
+    for (int i = 0; i < 3; ++i) { c.lo[i] = lo ? lo[i] : -0x40000000; c.hi[i] = hi ? hi[i] : 0x40000000; }
+    return c;
+}
+
+// Part 2: fan -> dose-grid transfer (:1185-1218) of the field's BEV dose — its own, or the slab another GPU exported —
+// into dev_dose, optionally restricted to a box of the dose grid (a GPU's slab of the plan's volume).
+int rtd_field_transfer(rtd_handle hh, rtd_field ff, float* dev_dose, const int32_t clip_min[3], const int32_t clip_max[3]) {
+    auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
+    auto* f = reinterpret_cast<rtd_field_impl*>(ff);
+    if (!h || !f || !dev_dose) return RTD_ERR_INVALID_ARG;
+    if (!f->computed) return fail(h, RTD_ERR_NOT_READY, "rtd_field_transfer: no BEV dose (compute the field or attach a slab first)");
+    RTD_HIP(h, hipSetDevice(h->device));
+    const FieldConst& fc = f->fc;
+    hipStream_t s = h->stream;
+    const dim3 blk(kSuperpTileX, kSuperpTileY);
+    const ClipBox clip = makeClip(clip_min, clip_max);
+    const float* bev = f->remote ? reinterpret_cast<const float*>(f->attached + kPackHeader) : f->dBev;
+    const FieldState* st = f->remote ? reinterpret_cast<const FieldState*>(f->attached) : f->dState;
     const int zChunk = 16;
     {
         // grid-stride over the bricks of the device-side box; never more blocks than bricks of the whole volume
         const size_t allBricks = (size_t)((f->doseDims[0] + 31) / 32) * ((f->doseDims[1] + 7) / 8) * ((f->doseDims[2] + zChunk - 1) / zChunk);
         const unsigned tg = (unsigned)std::min<size_t>(allBricks, (size_t)h->numCUs * 8 * 4);
         auto launchT = [&](auto kern) {
-            launchK(kern, dim3(tg), blk, 0, s, nullptr, f->ev[6], dev_dose, (int)f->doseDims[0], (int)f->doseDims[1],
-                    (int)f->doseDims[2], (const float*)f->dBev, (const FieldState*)f->dState, fc, zChunk);
+            launchK(kern, dim3(tg), blk, 0, s, f->remote ? f->ev[0] : nullptr, f->ev[6], dev_dose, (int)f->doseDims[0], (int)f->doseDims[1],
+                    (int)f->doseDims[2], bev, st, fc, zChunk, clip);
         };
         // lanes run along the dose axis that moves fastest along BEV x, so that the gathers stay within few BEV rows
         switch (f->transferMode) {
@@ -571,11 +685,17 @@ int rtd_field_compute(rtd_handle hh, rtd_field ff, float* dev_dose) {
         }
     }
     RTD_HIP(h, hipGetLastError());
-    f->computed = true;
+    f->transferred = true;
     return RTD_OK;
 }
 
-int rtd_field_clear_dose(rtd_handle hh, rtd_field ff, float* dev_dose) {
+int rtd_field_compute(rtd_handle hh, rtd_field ff, float* dev_dose) {
+    if (!dev_dose) return RTD_ERR_INVALID_ARG;
+    const int st = rtd_field_compute_bev(hh, ff);
+    return st != RTD_OK ? st : rtd_field_transfer(hh, ff, dev_dose, nullptr, nullptr);
+}
+
+int rtd_field_clear_dose_box(rtd_handle hh, rtd_field ff, float* dev_dose, const int32_t clip_min[3], const int32_t clip_max[3]) {
     auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
     auto* f = reinterpret_cast<rtd_field_impl*>(ff);
     if (!h || !f || !dev_dose) return RTD_ERR_INVALID_ARG;
@@ -584,8 +704,64 @@ int rtd_field_clear_dose(rtd_handle hh, rtd_field ff, float* dev_dose) {
     const int zChunk = 16;
     const size_t allBricks = (size_t)((f->doseDims[0] + 31) / 32) * ((f->doseDims[1] + 7) / 8) * ((f->doseDims[2] + zChunk - 1) / zChunk);
     const unsigned g = (unsigned)std::min<size_t>(allBricks, (size_t)h->numCUs * 8 * 4);
-    k_clear_box<<<g, dim3(kSuperpTileX, kSuperpTileY), 0, h->stream>>>(dev_dose, (int)f->doseDims[0], (int)f->doseDims[1], f->dState, zChunk);
+    const FieldState* st = f->remote ? reinterpret_cast<const FieldState*>(f->attached) : f->dState;
+    k_clear_box<<<g, dim3(kSuperpTileX, kSuperpTileY), 0, h->stream>>>(dev_dose, (int)f->doseDims[0], (int)f->doseDims[1], st, zChunk,
+                                                                       makeClip(clip_min, clip_max));
     RTD_HIP(h, hipGetLastError());
+    return RTD_OK;
+}
+
+int rtd_field_clear_dose(rtd_handle hh, rtd_field ff, float* dev_dose) { return rtd_field_clear_dose_box(hh, ff, dev_dose, nullptr, nullptr); }
+
+// ---- multi-GPU plans: a field's BEV slab travels, the receiving GPU transfers it into its slab of the dose volume ----
+
+// Waits for the field's device-side plan only (k_ks_plan: entry / passive steps, the BEV rectangle that carries dose, the dose
+// box) while the superposition still runs, and reports the size of the message rtd_field_export_bev will write.
+int rtd_field_wait_plan(rtd_handle hh, rtd_field ff, rtd_field_info* info, size_t* packed_bytes) {
+    auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
+    auto* f = reinterpret_cast<rtd_field_impl*>(ff);
+    if (!h || !f) return RTD_ERR_INVALID_ARG;
+    if (!f->computed || f->remote) return fail(h, RTD_ERR_NOT_READY, "rtd_field_wait_plan: field not computed on this handle");
+    RTD_HIP(h, hipSetDevice(h->device));
+    RTD_HIP(h, hipEventSynchronize(f->ev[4]));
+    const FieldState st = *f->hState;                                // mirrored by k_ks_plan into pinned host memory
+    if (info) fillInfo(f, st, info);
+    if (packed_bytes) {
+        const int nz = std::max(st.firstCalculatedPassive - st.beamFirstInside, 0);
+        const int x0 = std::max(st.bevLo[0] - 1, 0) & ~3, x1 = std::min(st.bevHi[0] + 1, f->fc.bevW - 1);
+        const int y0 = std::max(st.bevLo[1] - 1, 0), y1 = std::min(st.bevHi[1] + 1, f->fc.bevH - 1);
+        const bool none = nz == 0 || x1 < x0 || y1 < y0;
+        *packed_bytes = (size_t)kPackHeader + (none ? 0 : (size_t)nz * (y1 - y0 + 1) * ((x1 - x0 + 4) / 4) * 16);
+    }
+    return RTD_OK;
+}
+
+size_t rtd_bev_message_bound(rtd_handle hh, rtd_field ff) {
+    auto* f = reinterpret_cast<rtd_field_impl*>(ff);
+    (void)hh;
+    return f ? (size_t)kPackHeader + (size_t)f->fc.bevW * f->fc.bevH * (size_t)f->fc.S * sizeof(float) : 0;
+}
+
+int rtd_field_export_bev(rtd_handle hh, rtd_field ff, void* dev_buf, size_t capacity) {
+    auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
+    auto* f = reinterpret_cast<rtd_field_impl*>(ff);
+    if (!h || !f || !dev_buf || capacity < (size_t)kPackHeader) return RTD_ERR_INVALID_ARG;
+    if (!f->computed || f->remote) return fail(h, RTD_ERR_NOT_READY, "rtd_field_export_bev: field not computed on this handle");
+    RTD_HIP(h, hipSetDevice(h->device));
+    k_pack_bev<<<dim3((unsigned)h->numCUs * 4), dim3(256), 0, h->stream>>>((const float*)f->dBev, (const FieldState*)f->dState, f->fc,
+                                                                           reinterpret_cast<unsigned char*>(dev_buf), capacity);
+    RTD_HIP(h, hipGetLastError());
+    return RTD_OK;
+}
+
+int rtd_field_attach_bev(rtd_handle hh, rtd_field ff, const void* dev_buf) {
+    auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
+    auto* f = reinterpret_cast<rtd_field_impl*>(ff);
+    if (!h || !f || !dev_buf) return RTD_ERR_INVALID_ARG;
+    if (!f->remote) return fail(h, RTD_ERR_INVALID_ARG, "rtd_field_attach_bev: not a remote field (rtd_field_create_remote)");
+    f->attached = reinterpret_cast<const unsigned char*>(dev_buf);
+    f->computed = true;
+    f->transferred = false;
     return RTD_OK;
 }
 
@@ -598,11 +774,27 @@ int rtd_field_finish(rtd_handle hh, rtd_field ff, rtd_timing* timing, rtd_field_
     // next plan before finishing the previous one, and the device never idles on the host's bookkeeping. The state record was
     // mirrored into pinned host memory by k_ks_plan: no copy is issued here.
     RTD_HIP(h, hipSetDevice(h->device));
-    RTD_HIP(h, hipEventSynchronize(f->ev[6]));
+    if (f->remote) {
+        // a slab from another GPU: the state record is the message header (device memory) — copy it once the transfer is done
+        if (f->transferred) RTD_HIP(h, hipEventSynchronize(f->ev[6]));
+        FieldState st;
+        RTD_HIP(h, hipMemcpy(&st, f->attached, sizeof st, hipMemcpyDeviceToHost));
+        if (timing) {
+            std::memset(timing, 0, sizeof *timing);
+            if (f->transferred) { RTD_HIP(h, hipEventElapsedTime(&timing->transforming_ms, f->ev[0], f->ev[6])); timing->total_ms = timing->transforming_ms; }
+        }
+        if (info) fillInfo(f, st, info);
+        if (st.errorFlags & kErrPackOverflow) return fail(h, RTD_ERR_INVALID_ARG, "BEV message buffer too small for the exported slab");
+        if (st.errorFlags & kErrRadiusOverflow)
+            return fail(h, RTD_ERR_RADIUS_OVERFLOW, "Found larger than allowed kernel superposition radius");
+        return RTD_OK;
+    }
+    const int last = f->transferred ? 6 : 5;                         // BEV only: the superposition's reduce is the last kernel
+    RTD_HIP(h, hipEventSynchronize(f->ev[last]));
     const FieldState st = *f->hState;                                // mirrored by k_ks_plan into pinned host memory
     if (timing) {
         std::memset(timing, 0, sizeof *timing);
-        RTD_HIP(h, hipEventElapsedTime(&timing->total_ms, f->ev[0], f->ev[6]));
+        RTD_HIP(h, hipEventElapsedTime(&timing->total_ms, f->ev[0], f->ev[last]));
         if (h->opt.fine_grained_timing) {
             RTD_HIP(h, hipEventElapsedTime(&timing->raytracing_ms, f->ev[0], f->ev[1]));
             RTD_HIP(h, hipEventElapsedTime(&timing->prepare_energy_loop_ms, f->ev[1], f->ev[2]));
@@ -610,21 +802,11 @@ int rtd_field_finish(rtd_handle hh, rtd_field ff, rtd_timing* timing, rtd_field_
             RTD_HIP(h, hipEventElapsedTime(&timing->prepare_superp_ms, f->ev[3], f->ev[4]));
             RTD_HIP(h, hipEventElapsedTime(&timing->superp_ms, f->ev[4], f->ev[5]));
             RTD_HIP(h, hipEventElapsedTime(&timing->superp_kernel_ms, f->ev[8], f->ev[7]));
-            RTD_HIP(h, hipEventElapsedTime(&timing->transforming_ms, f->ev[5], f->ev[6]));
+            if (f->transferred) RTD_HIP(h, hipEventElapsedTime(&timing->transforming_ms, f->ev[5], f->ev[6]));
         }
         timing->superp_launches = 2;   // k_superpose_mfma + k_superpose_reduce (the reference: up to 33 per layer)
     }
-    if (info) {
-        std::memset(info, 0, sizeof *info);
-        info->ray_dims[0] = f->fc.W; info->ray_dims[1] = f->fc.H; info->ray_dims[2] = f->fc.L;
-        for (int i = 0; i < 3; ++i) { info->ray_offset[i] = f->fc.rayOffset[i]; info->ray_res[i] = f->fc.rayRes[i]; }
-        info->beam_first_inside = st.beamFirstInside; info->beam_first_outside = st.beamFirstOutside;
-        info->beam_first_guaranteed_passive = st.firstGuaranteedPassive;
-        info->beam_first_calculated_passive = st.firstCalculatedPassive;
-        for (int i = 0; i < 3; ++i) { info->bbox_min[i] = st.bboxMin[i]; info->bbox_max[i] = st.bboxMax[i]; }
-        for (int i = 0; i < 3; ++i) { info->dose_box_min[i] = st.tboxMin[i]; info->dose_box_max[i] = st.tboxMax[i]; }
-        info->live_steps = st.liveSteps; info->max_radius = st.maxRadius;
-    }
+    if (info) fillInfo(f, st, info);
     if (st.errorFlags & kErrRadiusOverflow)
         return fail(h, RTD_ERR_RADIUS_OVERFLOW, "Found larger than allowed kernel superposition radius");   // kernel_wrapper.cu:965
     return RTD_OK;
@@ -693,7 +875,7 @@ int rtd_compute(rtd_handle hh, const rtd_beam* beams, int n_beams, float* dose_i
         st = rtd_field_compute(hh, f, dDose);
         if (st == RTD_OK) st = rtd_field_finish(hh, f, timing ? &timing[i] : nullptr, nullptr);
         std::string keep = h->error;
-        rtd_field_destroy(hh, f);
+        rtd_field_release(hh, f);                                    // the next beam of the same shape reuses the workspace
         h->error = keep;
     }
     if (st == RTD_OK) {

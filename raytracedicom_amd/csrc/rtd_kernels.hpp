@@ -21,7 +21,7 @@ constexpr int kMaxLayers = 256;
 constexpr int kMaxSteps = 4096;
 constexpr int kNoRadius = 0xFF;
 
-enum FieldError : int { kErrRadiusOverflow = 1 };
+enum FieldError : int { kErrRadiusOverflow = 1, kErrPackOverflow = 2 };
 
 struct LutView {
     const float* density; int nDensity;
@@ -59,6 +59,10 @@ struct FieldState {
     int groupPassive[32];           // per superposition layer group: first step at which none of its layers deposits
     int actUnion[4];                // minima of (x, y, -x, -y) over all rays that carry dose in any (layer, step)
     int bevLo[2], bevHi[2];         // padded-BEV rectangle outside which every slice is exactly zero (transfer early-out)
+    // The slab the transfer samples: packW x packH pixels per slice, pixel (0, 0) = padded-BEV pixel (packX0, packY0), first
+    // slice = slice slabFirst of the buffer. The field's own BEV buffer: (0, 0, bevW, bevH, beamFirstInside); a slab exported
+    // by k_pack_bev for another GPU: the rectangle that carries dose, slices from 0.
+    int packX0, packY0, packW, packH, slabFirst;
     unsigned char fillOrder[256];           // energy layers by ascending number of steps to walk (k_plan), for k_fill's block placement
     unsigned char tileOrder[kKsMaxOrder];   // superposition dispatch order of the output tiles: most source rays in reach first
 };
@@ -110,6 +114,7 @@ __device__ inline float halfWaveMin(float v) {
 }
 __device__ inline int waveMinI(int v) { return waveReduce(v, [](int a, int b) { return b < a ? b : a; }); }
 __device__ inline int waveMaxI(int v) { return waveReduce(v, [](int a, int b) { return b > a ? b : a; }); }
+__device__ inline int roundToI(int v, int m) { return ((v + m - 1) / m) * m; }   // roundTo, kernel_wrapper.cu:45-48
 __device__ inline int f2iSat(float v) { return (int)v; }   // v_cvt_i32_f32: NaN -> 0, saturating (same as the reference GPU)
 
 // ------------------------------------------------------------------------------------------------
@@ -207,7 +212,8 @@ constexpr int kTraceSeg = 8;
 
 __global__ __launch_bounds__(256) void k_trace_sample(const float* __restrict__ ct, int nx, int ny, int nz, LutView lut,
                                                        TracerParams tp, int W, int H, float* __restrict__ bevDensity,
-                                                       float* __restrict__ spTerm, float* __restrict__ huBuf) {
+                                                       float* __restrict__ spTerm, float* __restrict__ huBuf,
+                                                       float* __restrict__ bevRrl, float rRlScale) {
     extern __shared__ float sLut[];
     float* sDensity = sLut;
     float* sSp = sLut + lut.nDensity;
@@ -239,8 +245,12 @@ __global__ __launch_bounds__(256) void k_trace_sample(const float* __restrict__ 
     for (unsigned int i = k0; i < k1; ++i) {
         const float huPlus1000 = sample3dBorder(ct, nx, ny, nz, pos.x, pos.y, pos.z);
         huBuf[idx] = huPlus1000;
-        bevDensity[idx] = sample1dClamp(sDensity, lut.nDensity, huPlus1000 * tp.densityScale);
+        const float density = sample1dClamp(sDensity, lut.nDensity, huPlus1000 * tp.densityScale);
+        bevDensity[idx] = density;
         spTerm[idx] = stepLen * sample1dClamp(sSp, lut.nSp, huPlus1000 * tp.spScale);
+        // density * (1/X0 per unit density): the radiation-length factor of the scatter term (kernel_wrapper.cu:285-290) does
+        // not depend on the energy layer, so it is evaluated here once per (ray, step) instead of once per layer in k_fill
+        bevRrl[idx] = density * sample1dClamp(lut.rrl, lut.nRrl, density * rRlScale);
         idx += memStep;
         pos = pos + step;
     }
@@ -257,7 +267,8 @@ __global__ __launch_bounds__(256) void k_trace_sample(const float* __restrict__ 
 constexpr int kTrRays = 16, kTrSteps = 512, kTrPitch = kTrSteps + 4;
 __global__ __launch_bounds__(64 * kTrRays) void k_trace_sample_t(const float* __restrict__ ct, int nx, int ny, int nz, LutView lut,
                                                                   TracerParams tp, int W, int H, float* __restrict__ bevDensity,
-                                                                  float* __restrict__ spTerm, float* __restrict__ huBuf) {
+                                                                  float* __restrict__ spTerm, float* __restrict__ huBuf,
+                                                                  float* __restrict__ bevRrl, float rRlScale) {
     extern __shared__ float sLut[];
     float* sDensity = sLut;
     float* sSp = sLut + lut.nDensity;
@@ -302,8 +313,10 @@ __global__ __launch_bounds__(64 * kTrRays) void k_trace_sample_t(const float* __
                 if (k < tp.steps) {
                     const size_t idx = (size_t)k * memStep + ray0 + oRay;
                     huBuf[idx] = oHu[sl];
-                    bevDensity[idx] = oDe[sl];
+                    const float density = oDe[sl];
+                    bevDensity[idx] = density;
                     spTerm[idx] = oSp[sl];
+                    bevRrl[idx] = density * sample1dClamp(lut.rrl, lut.nRrl, density * rRlScale);   // (see k_trace_sample)
                 }
             }
         __syncthreads();
@@ -514,214 +527,255 @@ __global__ void k_conv_y(const float* __restrict__ in, float* __restrict__ out, 
 
 // ------------------------------------------------------------------------------------------------
 // K5: IDD + sigma fill = fillIddAndSigma without NUCLEAR_CORR (kernel_wrapper.cu:190-379), all energy layers in
-// one launch (blockIdx.z = layer), fused with the reductions and the classification that follow it in the
-// reference: layerFirstPassive (sliceMaxVar, :952-957) and the per-tile radius class + histogram (tileRadCalc,
-// kernel_wrapper.cuh:256-313). Block = one 32x8 classification tile = 4 waves. The layer's two cumulative-IDD
-// rows and the 1/X0 table are staged in LDS (the reference fetches them through textures, :269-274,:285-290);
-// WEPL and density of the next step are prefetched while the current step's serial recurrence runs. The
-// recurrence itself keeps the reference's order ("a bit of a mine field", kernel_wrapper.cuh:144).
+// one launch, fused with the reductions and the classification that follow it in the reference: layerFirstPassive
+// (sliceMaxVar, :952-957) and the per-tile radius class + histogram (tileRadCalc, kernel_wrapper.cuh:256-313).
+//
+// Block = one (layer, 32x8 classification tile, ROLE) = 4 waves: every ray is walked by TWO threads (of different blocks).
+// The reference's step computes two things that share nothing but the liveness of the ray (a function of WEPL alone):
+//   role 0, the sigma walk:  residual-range power, betaP, thetaSq and the serial sums sigmaSq / incScat / incincScat /
+//                            incDiv (:276-303) -> 1/sigma; per batch of steps the tile's radius class and histogram;
+//   role 1, the dose walk:   cumulative-IDD lookup (:269-274), mass and the dose value (:305-322); per batch the rectangle
+//                            of the tile's rays that carry dose.
+// The serial chains exist once per (ray, layer) — L*R/64 = 2640 waves on C3, 2.6 per SIMD — which is why the single-role form
+// of this kernel sat at 61 % of its own instruction-issue bound; two roles double the waves per SIMD and halve each chain.
+//
+// INDEX WORK IS BIT-EXACT. 1/sigma feeds an integer: the tile minimum is thresholded into the radius class. Everything the
+// class depends on is therefore computed with correctly rounded IEEE operations in the reference's order: the power with
+// rtd_pow_det (include/rtd_detmath.h, shared with the host-side checker of the test suite — the reference's __powf is a hardware approximation),
+// both divisions of betaP / thetaSq with IEEE division, the sums as written. The per-ray 1/sigma that the superposition reads
+// for its weights uses the hardware sqrt / reciprocal (<= 2 ulp; the reference builds with -use_fast_math), but the tile's class
+// does not come from those values: x -> step/(sqrt2*(sqrt(x)+delta)) is monotone under correct rounding, so the tile
+// minimum of the exact 1/sigma equals that function of the tile MAXIMUM of sigmaSq, evaluated once per (step, tile) with
+// IEEE sqrt and division.
+#define RTD_DM_FN __device__ inline
+#include "../../include/rtd_detmath.h"
+
+constexpr int kFillBatch = 8;   // steps per batch: inputs fetched one batch ahead, one block barrier per batch
+
 template <bool LDS_LUT>
 __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensity, const float* __restrict__ bevCumulSp,
+                                               const float* __restrict__ bevRrl,
                                                float* __restrict__ bevIdd, float* __restrict__ bevRSigmaEff,
                                                const float* __restrict__ rayWeights, const int* __restrict__ firstInside,
                                                const int* __restrict__ firstOutside, int* __restrict__ firstPassive,
                                                unsigned char* __restrict__ tileRad, LayerPlan* layers, FieldState* st,
                                                LutView lut, FillGeom fg, FieldConst fc, const float* __restrict__ stepTab,
                                                int* __restrict__ active, int nCU) {
-    extern __shared__ float sLutF[];
-    __shared__ float sRs[2][8][256];                                 // [buffer][step][ray] 1/sigma of the batch's steps, for the tile minimum
-    __shared__ unsigned long long sDoseMask[2][8][4];                // [buffer][step][wave] ballot of the rays that carry dose
+    extern __shared__ float sLutF[];                                 // dose walk: the layer's two cumulative-IDD rows
+    __shared__ float sSig[2][kFillBatch][256];                       // sigma walk: [buffer][step][ray] sigmaSq of the rays with a finite 1/sigma (-1: none)
+    __shared__ unsigned long long sDoseMask[2][kFillBatch][4];       // dose walk: [buffer][step][wave] ballot of the rays that carry dose
     __shared__ int sHist[kMaxSuperpR + 2];
 
-    // Block placement. The kernel is bound by vector-instruction throughput and the number of steps differs per layer
-    // (150..210 on C3), while only L*tiles blocks exist (2.6 per CU on C3): with a plain grid the CUs that receive 3 blocks
-    // of long layers set the kernel time and the others idle (measured: 148 CUs x 3 blocks, 108 x 2; 409 k vs 285 k cycles).
-    // When all blocks are co-resident the dispatcher places block b on CU b % nCU (measured), so the (layer, tile) items,
-    // taken in ascending order of steps, are dealt so that the CUs with one block more get the shortest items.
-    const int nTiles = fc.tilesX * fc.tilesY, nB = nTiles * fc.L;
+    // Block placement. The number of steps differs per layer (150..210 on C3) and a sigma walk is about twice a dose walk,
+    // while only 2*L*tiles blocks exist (5.2 per CU on C3): with a plain grid the CUs that receive the long items set the
+    // kernel time and the others idle. When all blocks are co-resident the dispatcher places block b on CU b % nCU (measured),
+    // so the items, taken in ascending order of cost (layers by steps; per layer the dose walks, then the sigma walks), are
+    // dealt so that the CUs with one block more get the shortest items. (Performance only: any placement gives the same result.)
+    const int nTiles = fc.tilesX * fc.tilesY, nB = 2 * nTiles * fc.L;
     int item = blockIdx.x;
-    if (nB <= 4 * nCU) {
+    if (nB <= 6 * nCU) {
         const int q = nB / nCU, r = nB - q * nCU, c = blockIdx.x % nCU, rr = blockIdx.x / nCU;
         item = c < r ? (q + 1) * c + rr : (q + 1) * r + q * (c - r) + rr;
     } else {
         item = nB - 1 - item;                                        // many rounds of blocks: longest first
     }
-    const int layer = st->fillOrder[item / nTiles];
+    const int layer = st->fillOrder[item / (2 * nTiles)];
+    const int role = (item % (2 * nTiles)) < nTiles ? 1 : 0;         // block-uniform: 0 sigma walk, 1 dose walk
     const int tileNo = item % nTiles, tileX = tileNo % fc.tilesX, tileY = tileNo / fc.tilesX;
-    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    const int tid = threadIdx.y * 32 + threadIdx.x;                  // ray of the tile
     const int wave = tid >> 6;
-    const int x = tileX * blockDim.x + threadIdx.x;
-    const int y = tileY * blockDim.y + threadIdx.y;
+    const int x = tileX * kSuperpTileX + threadIdx.x;
+    const int y = tileY * kSuperpTileY + threadIdx.y;
     const int W = fc.W, H = fc.H;
     const size_t memStep = (size_t)W * H;
     const size_t layerOff = (size_t)layer * memStep * fc.S;
     const size_t rayIdx = (size_t)y * W + x;
+    const unsigned int rayOff = (unsigned int)rayIdx;
 
     const LayerPlan lp = layers[layer];
-    // cumulative IDD: rows floor(energyIdx), floor(energyIdx)+1 (CLAMP) and the row weight are layer constants
-    int ey0, ey1; float eay;
-    {
-        float py = lp.energyIdx, fy = floorf(py);
-        eay = py - fy; ey0 = (int)fy; ey1 = ey0 + 1;
-        if (!(py >= 0.0f)) { ey0 = 0; ey1 = 0; eay = 0.0f; }
-        ey0 = ey0 > lut.nEnergies - 1 ? lut.nEnergies - 1 : ey0;
-        ey1 = ey1 > lut.nEnergies - 1 ? lut.nEnergies - 1 : ey1;
-    }
-    const float* gRow0 = lut.cidd + (size_t)ey0 * lut.nSamples;
-    const float* gRow1 = lut.cidd + (size_t)ey1 * lut.nSamples;
-    float* sRow0 = sLutF;
-    float* sRow1 = sLutF + lut.nSamples;
-    float* sRrl = sLutF + 2 * lut.nSamples;
-    if (LDS_LUT) {
-        for (int i = tid; i < lut.nSamples; i += 256) { sRow0[i] = gRow0[i]; sRow1[i] = gRow1[i]; }
-        for (int i = tid; i < lut.nRrl; i += 256) sRrl[i] = lut.rrl[i];
-    }
-    if (tid < kMaxSuperpR + 2) sHist[tid] = 0;
-
     const unsigned int pFirst = (unsigned int)st->beamFirstInside;
     const unsigned int pAfterLast = st->empty ? pFirst : (unsigned int)lp.afterLast;
 
+    // liveness of the ray (:236-243, :308-311): a function of WEPL, the ray weight and the cut-off steps — both roles track it
     bool beamLive = true;
     const int firstIn = firstInside[rayIdx];
-    int fo = firstOutside[rayIdx];
+    const int fo = firstOutside[rayIdx];
     unsigned int afterLast = (unsigned int)(fo < (int)pAfterLast ? fo : (int)pAfterLast);
     const float rayWeight = rayWeights[(size_t)layer * memStep + rayIdx];
     if (rayWeight < fc.rayWeightCutoff || afterLast < pFirst) { beamLive = false; afterLast = 0; }
+    const float cutDepth = lp.peakDepth * fc.bpDepthCutoff;
+    float cumulSpOld = 0.0f;
+    const float sqrt2 = 1.41421356f, sigmaDelta = 0.21f;
 
-    float res = 0.0f, rSigmaEff = 0.0f, cumulSp, cumulSpOld = 0.0f, cumulDose, cumulDoseOld = 0.0f;
-    const float pInv = 0.5649718f, eCoef = 8.639415f, sqrt2 = 1.41421356f;
-    const float eRefSq = 198.81f, sigmaDelta = 0.21f;
-    float incScat = 0.0f, incincScat = 0.0f;
-    float incDiv = lp.sigmaSqAirLin + (2.0f * (float)pFirst - 1.0f) * lp.sigmaSqAirQuad;
-    float sigmaSq = -incDiv;
-    __syncthreads();
-
-    int actUni = 0x7fffffff;
-    constexpr int kFillBatch = 8;   // WEPL/density of a batch of steps are loaded up front (independent of the recurrence)
-    // WEPL / density are fetched one batch ahead of the walk (a round trip per batch was 290 cycles per step)
-    float spN[kFillBatch], denN[kFillBatch];
-    const unsigned int rayOff = (unsigned int)rayIdx;
-    auto fetch = [&](unsigned int s0) {
+    if (role == 0) {
+        // ================================ sigma walk ================================
+        if (tid < kMaxSuperpR + 2) sHist[tid] = 0;
+        const float pInv = 0.5649718f, eCoef = 8.639415f, eRefSq = 198.81f;
+        float rSigmaEff = 0.0f, incScat = 0.0f, incincScat = 0.0f;
+        float incDiv = lp.sigmaSqAirLin + (2.0f * (float)pFirst - 1.0f) * lp.sigmaSqAirQuad;
+        float sigmaSq = -incDiv;
+        // Inputs are fetched one batch ahead of the walk (a round trip per batch was 290 cycles per step), in a rolling fashion:
+        // as soon as a step has consumed its register slot, the slot takes the load of the step one batch later.
+        float spB[kFillBatch], denB[kFillBatch], rrlB[kFillBatch];
+        auto fetch1 = [&](int j, unsigned int stepNo) {              // wave-uniform slice base + the lane's ray offset
+            spB[j] = 0.0f; denB[j] = 0.0f; rrlB[j] = 0.0f;
+            if (stepNo < pAfterLast) {
+                spB[j] = (bevCumulSp + (size_t)stepNo * memStep)[rayOff];
+                denB[j] = (bevDensity + (size_t)stepNo * memStep)[rayOff];
+                rrlB[j] = (bevRrl + (size_t)stepNo * memStep)[rayOff];
+            }
+        };
 #pragma unroll
-        for (int j = 0; j < kFillBatch; ++j) {                       // wave-uniform slice base + the lane's ray offset
-            spN[j] = 0.0f; denN[j] = 0.0f;
-            if (s0 + j < pAfterLast) {
-                spN[j] = (bevCumulSp + (size_t)(s0 + j) * memStep)[rayOff];
-                denN[j] = (bevDensity + (size_t)(s0 + j) * memStep)[rayOff];
+        for (int j = 0; j < kFillBatch; ++j) fetch1(j, pFirst + j);
+        __syncthreads();
+        int buf = 0;
+        for (unsigned int step0 = pFirst; step0 < pAfterLast; step0 += kFillBatch, buf ^= 1) {
+#pragma unroll
+            for (int j = 0; j < kFillBatch; ++j) {
+                const unsigned int stepNo = step0 + j;
+                if (stepNo >= pAfterLast) { sSig[buf][j][tid] = -1.0f; continue; }   // block-uniform
+                const float cumulSp = spB[j], density = denB[j], rRl = rrlB[j];
+                fetch1(j, stepNo + kFillBatch);
+                if (beamLive) {
+                    if (cumulSp < lp.peakDepth) {
+                        const float resE = eCoef * rtd_pow_det(lp.peakDepth - 0.5f * (cumulSp + cumulSpOld), pInv);
+                        const float betaP = resE + 938.3f - 938.3f * 938.3f / (resE + 938.3f);
+                        const float thetaSq = eRefSq / (betaP * betaP) * fg.stepLength * rRl;
+                        sigmaSq += incScat + incDiv;
+                        incincScat += 2.0f * thetaSq * fg.stepLength * fg.stepLength;
+                        incScat += incincScat;
+                        incDiv += 2.0f * lp.sigmaSqAirQuad;
+                    } else {
+                        sigmaSq -= 1.5f * (incScat + incDiv) * density;
+                    }
+                    // stepTab[2k] = 0.5*(voxelWidth(k).x + voxelWidth(k).y): per-step constant evaluated once on the host with the
+                    // reference's expressions (fill_idd_and_sigma_params.cu:42-46). Hardware sqrt / reciprocal: this value only
+                    // weights the superposition; the radius class comes from sigmaSq itself (below).
+                    rSigmaEff = stepTab[2 * stepNo] * __builtin_amdgcn_rcpf(sqrt2 * (__builtin_amdgcn_sqrtf(sigmaSq) + sigmaDelta));
+                    if (cumulSp > cutDepth || stepNo == afterLast) { beamLive = false; afterLast = stepNo; }
+                    cumulSpOld = cumulSp;
+                }
+                float sig = sigmaSq;
+                if (!beamLive || (int)stepNo < (firstIn - 1)) { rSigmaEff = __int_as_float(0x7f800000); sig = -1.0f; }
+                (bevRSigmaEff + layerOff + (size_t)stepNo * memStep)[rayOff] = rSigmaEff;
+                sSig[buf][j][tid] = sig;
+            }
+            __syncthreads();                                         // the only barrier of a batch (sSig is double-buffered)
+            {   // fused tileRadCalc: radius class of every (layer, step, tile) of the batch, 32 lanes per step
+                const int j = tid >> 5, l = tid & 31;                // step of the batch, lane of its 32-lane group
+                float m = sSig[buf][j][l];
+#pragma unroll
+                for (int k = 1; k < 8; ++k) { const float t = sSig[buf][j][l + 32 * k]; m = t > m ? t : m; }
+                m = -halfWaveMin(-m);                                // lanes 31 / 63 hold the maximum of their 32-lane half
+                if (l == 31 && step0 + j < pAfterLast) {
+                    // tile minimum of 1/sigma (= the reference's minVal, kernel_wrapper.cuh:282-297) from the tile maximum of
+                    // sigmaSq with IEEE sqrt and division, then the class exactly as the reference computes it (:300-305)
+                    const float minRs = m >= 0.0f ? stepTab[2 * (step0 + j)] / (sqrt2 * (sqrtf(m) + sigmaDelta)) : __int_as_float(0x7f800000);
+                    int rad = f2iSat(fc.ksSigmaCutoff / (sqrtf(2.0f) * minRs) + 0.5f);
+                    rad = rad > kMaxSuperpR + 1 ? kMaxSuperpR + 1 : rad;
+                    rad = rad < 0 ? 0 : rad;
+                    tileRad[((size_t)layer * fc.S + step0 + j) * nTiles + tileNo] = (unsigned char)rad;
+                    atomicAdd(&sHist[rad], 1);
+                }
             }
         }
-    };
-    if (pFirst < pAfterLast) fetch(pFirst);
-    int buf = 0;
-    for (unsigned int step0 = pFirst; step0 < pAfterLast; step0 += kFillBatch, buf ^= 1) {
-      float spB[kFillBatch], denB[kFillBatch], rsB[kFillBatch];
-      unsigned long long doseMask[kFillBatch];
-#pragma unroll
-      for (int j = 0; j < kFillBatch; ++j) { spB[j] = spN[j]; denB[j] = denN[j]; }
-      if (step0 + kFillBatch < pAfterLast) fetch(step0 + kFillBatch);
-#pragma unroll
-      for (int j = 0; j < kFillBatch; ++j) {
-        const unsigned int stepNo = step0 + j;
-        rsB[j] = __int_as_float(0x7f800000);
-        doseMask[j] = 0ull;
-        if (stepNo >= pAfterLast) continue;                          // block-uniform
-        const float curSp = spB[j], curDensity = denB[j];
-        if (beamLive) {
-            cumulSp = curSp;
-            {   // tex2D(cumulIddTex, ...) :269-274, rows and row weight hoisted
-                float px = cumulSp * lp.energyScaleFact;
-                float fx = floorf(px), ax = px - fx;
-                int x0 = (int)fx, x1 = x0 + 1;
-                if (!(px >= 0.0f)) { x0 = 0; x1 = 0; ax = 0.0f; }
-                x0 = x0 > lut.nSamples - 1 ? lut.nSamples - 1 : x0; x1 = x1 > lut.nSamples - 1 ? lut.nSamples - 1 : x1;
-                float r0 = LDS_LUT ? lerpW(ax, sRow0[x0], sRow0[x1]) : lerpW(ax, gRow0[x0], gRow0[x1]);
-                float r1 = LDS_LUT ? lerpW(ax, sRow1[x0], sRow1[x1]) : lerpW(ax, gRow1[x0], gRow1[x1]);
-                cumulDose = lerpW(eay, r0, r1);
-            }
-            float density = curDensity;
-            if (cumulSp < lp.peakDepth) {
-                // the reference calls __powf (kernel_wrapper.cu:282) = 2^(y*log2(x)) on the special-function unit; same form here
-                float resE = eCoef * __builtin_amdgcn_exp2f(pInv * __builtin_amdgcn_logf(lp.peakDepth - 0.5f * (cumulSp + cumulSpOld)));
-                // divisions and the square root of this kernel use the hardware reciprocal / sqrt (<= 1-2 ulp): the reference is
-                // built with -use_fast_math (CMakeLists.txt:52-55), where they are approximate too; no comparison or
-                // branch below depends on them
-                float betaP = resE + 938.3f - 938.3f * 938.3f * __builtin_amdgcn_rcpf(resE + 938.3f);
-                float rRl = density * (LDS_LUT ? sample1dClamp(sRrl, lut.nRrl, density * fg.rRlScale)
-                                               : sample1dClamp(lut.rrl, lut.nRrl, density * fg.rRlScale));
-                float thetaSq = eRefSq * __builtin_amdgcn_rcpf(betaP * betaP) * fg.stepLength * rRl;
-                sigmaSq += incScat + incDiv;
-                incincScat += 2.0f * thetaSq * fg.stepLength * fg.stepLength;
-                incScat += incincScat;
-                incDiv += 2.0f * lp.sigmaSqAirQuad;
-            } else {
-                sigmaSq -= 1.5f * (incScat + incDiv) * density;
-            }
-            // stepTab[2k] = 0.5*(voxelWidth(k).x + voxelWidth(k).y), stepTab[2k+1] = stepVol(k): per-step constants evaluated once
-            // on the host with the reference's expressions (fill_idd_and_sigma_params.cu:42-46,72)
-            rSigmaEff = stepTab[2 * stepNo] * __builtin_amdgcn_rcpf(sqrt2 * (__builtin_amdgcn_sqrtf(sigmaSq) + sigmaDelta));
-            if (cumulSp > lp.peakDepth * fc.bpDepthCutoff || stepNo == afterLast) { beamLive = false; afterLast = stepNo; }
-            const float stepVol = stepTab[2 * stepNo + 1];
-            float mass = fc.doseToWater ? (cumulSp - cumulSpOld) * stepVol : density * stepVol;
-            if (mass > 1e-2f) res = rayWeight * (cumulDose - cumulDoseOld) * __builtin_amdgcn_rcpf(mass);
-            cumulSpOld = cumulSp;
-            cumulDoseOld = cumulDose;
+        firstPassive[(size_t)layer * memStep + rayIdx] = (int)afterLast;
+        int mx = waveMaxI((int)afterLast);
+        if ((tid & (kWave - 1)) == 0) atomicMax(&layers[layer].layerFirstPassive, mx);
+        __syncthreads();
+        if (tid < kMaxSuperpR + 2 && sHist[tid] > 0) atomicAdd(&layers[layer].hist[tid], sHist[tid]);
+    } else {
+        // ================================ dose walk ================================
+        // cumulative IDD: rows floor(energyIdx), floor(energyIdx)+1 (CLAMP) and the row weight are layer constants
+        int ey0, ey1; float eay;
+        {
+            float py = lp.energyIdx, fy = floorf(py);
+            eay = py - fy; ey0 = (int)fy; ey1 = ey0 + 1;
+            if (!(py >= 0.0f)) { ey0 = 0; ey1 = 0; eay = 0.0f; }
+            ey0 = ey0 > lut.nEnergies - 1 ? lut.nEnergies - 1 : ey0;
+            ey1 = ey1 > lut.nEnergies - 1 ? lut.nEnergies - 1 : ey1;
         }
-        if (!beamLive || (int)stepNo < (firstIn - 1)) { res = 0.0f; rSigmaEff = __int_as_float(0x7f800000); }
-        (bevIdd + layerOff + (size_t)stepNo * memStep)[rayOff] = res;
-        (bevRSigmaEff + layerOff + (size_t)stepNo * memStep)[rayOff] = rSigmaEff;
-
-        rsB[j] = rSigmaEff;
-        doseMask[j] = __ballot(res > 0.0f);
-      }
-      // fused tileRadCalc: min of 1/sigma over the 32x8 tile -> radius class of every (layer, step, tile) of the batch.
-      // The batch's values go through LDS once and 32 lanes per step reduce them after the barrier (eight per-wave DPP
-      // reductions per batch, one per step, cost 600 cycles per step on the walk's critical path).
+        const float* gRow0 = lut.cidd + (size_t)ey0 * lut.nSamples;
+        const float* gRow1 = lut.cidd + (size_t)ey1 * lut.nSamples;
+        float* sRow0 = sLutF;
+        float* sRow1 = sLutF + lut.nSamples;
+        if (LDS_LUT) for (int i = tid; i < lut.nSamples; i += 256) { sRow0[i] = gRow0[i]; sRow1[i] = gRow1[i]; }
+        float res = 0.0f, cumulDoseOld = 0.0f;
+        int actUni = 0x7fffffff;
+        float spB[kFillBatch], denB[kFillBatch];
+        auto fetch1 = [&](int j, unsigned int stepNo) {
+            spB[j] = 0.0f; denB[j] = 0.0f;
+            if (stepNo < pAfterLast) {
+                spB[j] = (bevCumulSp + (size_t)stepNo * memStep)[rayOff];
+                if (!fc.doseToWater) denB[j] = (bevDensity + (size_t)stepNo * memStep)[rayOff];
+            }
+        };
 #pragma unroll
-      for (int j = 0; j < kFillBatch; ++j) {
-          sRs[buf][j][tid] = rsB[j];
-          if ((tid & (kWave - 1)) == 0) sDoseMask[buf][j][wave] = doseMask[j];
-      }
-      __syncthreads();                                               // the only barrier of a batch (exchange arrays are double-buffered)
-      {
-          const int j = tid >> 5, l = tid & 31;                      // step of the batch, lane of its 32-lane group
-          float m = sRs[buf][j][l];
+        for (int j = 0; j < kFillBatch; ++j) fetch1(j, pFirst + j);
+        __syncthreads();
+        int buf = 0;
+        for (unsigned int step0 = pFirst; step0 < pAfterLast; step0 += kFillBatch, buf ^= 1) {
+            unsigned long long doseMask[kFillBatch];
 #pragma unroll
-          for (int k = 1; k < 8; ++k) { const float t = sRs[buf][j][l + 32 * k]; m = t < m ? t : m; }
-          m = halfWaveMin(m);                                        // lanes 31 / 63 hold the minimum of their 32-lane half
-          if (l == 31 && step0 + j < pAfterLast) {
-              int rad = f2iSat(fc.ksSigmaCutoff / (sqrtf(2.0f) * m) + 0.5f);
-              rad = rad > kMaxSuperpR + 1 ? kMaxSuperpR + 1 : rad;
-              rad = rad < 0 ? 0 : rad;
-              tileRad[((size_t)layer * fc.S + step0 + j) * nTiles + tileNo] = (unsigned char)rad;
-              atomicAdd(&sHist[rad], 1);
-          }
-          // rectangle of the tile's rays that carry dose at step j, as minima of (x, y, -x, -y): lanes 0..3 of the step's group,
-          // one component each, from the four waves' ballots (wave w holds rows 2w, 2w+1 of the tile: low / high 32 bits)
-          if (l < 4 && step0 + j < pAfterLast) {
-              unsigned int colMask = 0u, rowMask = 0u;               // columns / rows of the tile with dose
+            for (int j = 0; j < kFillBatch; ++j) {
+                const unsigned int stepNo = step0 + j;
+                doseMask[j] = 0ull;
+                if (stepNo >= pAfterLast) continue;                  // block-uniform
+                const float cumulSp = spB[j], density = denB[j];
+                fetch1(j, stepNo + kFillBatch);
+                if (beamLive) {
+                    float cumulDose;
+                    {   // tex2D(cumulIddTex, ...) :269-274, rows and row weight hoisted
+                        float px = cumulSp * lp.energyScaleFact;
+                        float fx = floorf(px), ax = px - fx;
+                        int x0 = (int)fx, x1 = x0 + 1;
+                        if (!(px >= 0.0f)) { x0 = 0; x1 = 0; ax = 0.0f; }
+                        x0 = x0 > lut.nSamples - 1 ? lut.nSamples - 1 : x0; x1 = x1 > lut.nSamples - 1 ? lut.nSamples - 1 : x1;
+                        float r0 = LDS_LUT ? lerpW(ax, sRow0[x0], sRow0[x1]) : lerpW(ax, gRow0[x0], gRow0[x1]);
+                        float r1 = LDS_LUT ? lerpW(ax, sRow1[x0], sRow1[x1]) : lerpW(ax, gRow1[x0], gRow1[x1]);
+                        cumulDose = lerpW(eay, r0, r1);
+                    }
+                    if (cumulSp > cutDepth || stepNo == afterLast) { beamLive = false; afterLast = stepNo; }
+                    // stepTab[2k+1] = stepVol(k) (fill_idd_and_sigma_params.cu:72)
+                    const float stepVol = stepTab[2 * stepNo + 1];
+                    const float mass = fc.doseToWater ? (cumulSp - cumulSpOld) * stepVol : density * stepVol;
+                    // (the dose value feeds no threshold other than res > 0, which a reciprocal cannot change: hardware reciprocal, <= 1 ulp)
+                    if (mass > 1e-2f) res = rayWeight * (cumulDose - cumulDoseOld) * __builtin_amdgcn_rcpf(mass);
+                    cumulSpOld = cumulSp;
+                    cumulDoseOld = cumulDose;
+                }
+                if (!beamLive || (int)stepNo < (firstIn - 1)) res = 0.0f;
+                (bevIdd + layerOff + (size_t)stepNo * memStep)[rayOff] = res;
+                doseMask[j] = __ballot(res > 0.0f);
+            }
+            if ((tid & (kWave - 1)) == 0) {
 #pragma unroll
-              for (int w = 0; w < 4; ++w) {
-                  const unsigned long long dm = sDoseMask[buf][j][w];
-                  const unsigned int lo = (unsigned int)dm, hi = (unsigned int)(dm >> 32);
-                  colMask |= lo | hi;
-                  rowMask |= (lo ? 1u : 0u) << (2 * w) | (hi ? 1u : 0u) << (2 * w + 1);
-              }
-              if (colMask) {
-                  const int x0t = tileX * kSuperpTileX, y0t = tileY * kSuperpTileY;
-                  const int v = l == 0 ? x0t + __builtin_ctz(colMask) : l == 1 ? y0t + __builtin_ctz(rowMask)
-                              : l == 2 ? -(x0t + 31 - __builtin_clz(colMask)) : -(y0t + 31 - __builtin_clz(rowMask));
-                  atomicMin(&active[((size_t)layer * fc.S + step0 + j) * 4 + l], v);
-                  actUni = min(actUni, v);
-              }
-          }
-      }
+                for (int j = 0; j < kFillBatch; ++j) sDoseMask[buf][j][wave] = doseMask[j];
+            }
+            __syncthreads();                                         // the only barrier of a batch (sDoseMask is double-buffered)
+            // rectangle of the tile's rays that carry dose at step j, as minima of (x, y, -x, -y): lanes 0..3 of the step's group,
+            // one component each, from the four waves' ballots (wave w holds rows 2w, 2w+1 of the tile: low / high 32 bits)
+            const int j = tid >> 5, l = tid & 31;
+            if (l < 4 && step0 + j < pAfterLast) {
+                unsigned int colMask = 0u, rowMask = 0u;             // columns / rows of the tile with dose
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const unsigned long long dm = sDoseMask[buf][j][w];
+                    const unsigned int lo = (unsigned int)dm, hi = (unsigned int)(dm >> 32);
+                    colMask |= lo | hi;
+                    rowMask |= (lo ? 1u : 0u) << (2 * w) | (hi ? 1u : 0u) << (2 * w + 1);
+                }
+                if (colMask) {
+                    const int x0t = tileX * kSuperpTileX, y0t = tileY * kSuperpTileY;
+                    const int v = l == 0 ? x0t + __builtin_ctz(colMask) : l == 1 ? y0t + __builtin_ctz(rowMask)
+                                : l == 2 ? -(x0t + 31 - __builtin_clz(colMask)) : -(y0t + 31 - __builtin_clz(rowMask));
+                    atomicMin(&active[((size_t)layer * fc.S + step0 + j) * 4 + l], v);
+                    actUni = min(actUni, v);
+                }
+            }
+        }
+        if ((tid & 31) < 4 && actUni != 0x7fffffff) atomicMin(&st->actUnion[tid & 3], actUni);
     }
-    firstPassive[(size_t)layer * memStep + rayIdx] = (int)afterLast;
-    int mx = waveMaxI((int)afterLast);
-    if ((tid & (kWave - 1)) == 0) atomicMax(&layers[layer].layerFirstPassive, mx);
-    __syncthreads();
-    if (tid < kMaxSuperpR + 2 && sHist[tid] > 0) atomicAdd(&layers[layer].hist[tid], sHist[tid]);
-    if ((tid & 31) < 4 && actUni != 0x7fffffff) atomicMin(&st->actUnion[tid & 3], actUni);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -799,6 +853,7 @@ __global__ void k_ks_plan(FieldState* st, LayerPlan* layers, FieldConst fc, From
         st->bevLo[0] = st->actUnion[0] + 32 - rr; st->bevLo[1] = st->actUnion[1] + 32 - rr;
         st->bevHi[0] = -st->actUnion[2] + 32 + rr; st->bevHi[1] = -st->actUnion[3] + 32 + rr;
         st->liveSteps = (long long)sLive;
+        st->packX0 = 0; st->packY0 = 0; st->packW = fc.bevW; st->packH = fc.bevH; st->slabFirst = first;
         TransferParams tp = tp0;
         tp.globalOffset.z = tp0.globalOffset.z + (-(float)first);   // invertAndShift(..., -beamFirstInside) :1213
         st->transfer = tp;
@@ -819,13 +874,21 @@ __global__ void k_ks_plan(FieldState* st, LayerPlan* layers, FieldConst fc, From
             t = (int)ceilf(maxP.x); st->bboxMax[0] = t < doseNx - 1 ? t : doseNx - 1;
             t = (int)ceilf(maxP.y); st->bboxMax[1] = t < doseNy - 1 ? t : doseNy - 1;
             t = (int)ceilf(maxP.z); st->bboxMax[2] = t < doseNz - 1 ? t : doseNz - 1;
-            // the BEV dose is exactly zero outside the padded rectangle [bevLo, bevHi] (+-1 px of interpolation reach): its
-            // image bounds the voxels the transfer can change
+            // The voxels primTransfDiv visits (kernel_wrapper.cu:69-97, launch :1209-1214): its grid starts at minIdx and is rounded up
+            // to whole 32 x 8 blocks, clipped by the dose dimensions only — x and y run PAST maxIdx up to the block edge — while z
+            // stops at maxIdx.z. Voxels between maxIdx and the block edge do receive dose when the interpolated BEV value there
+            // is non-zero (one BEV step beyond the last slice still interpolates against it), so the coverage is kept exactly.
+            const int covMax[3] = { min(st->bboxMin[0] + roundToI(st->bboxMax[0] - st->bboxMin[0] + 1, 32) - 1, doseNx - 1),
+                                    min(st->bboxMin[1] + roundToI(st->bboxMax[1] - st->bboxMin[1] + 1, 8) - 1, doseNy - 1), st->bboxMax[2] };
+            // the BEV dose is exactly zero outside the padded rectangle [bevLo, bevHi] and outside the slices [first, calcPassive):
+            // the image of that block, grown by the interpolation reach (one pixel / one step on every side), bounds the voxels
+            // the transfer can change
             float txVals[2] = { (float)(st->bevLo[0] - 32 - 1), (float)(st->bevHi[0] - 32 + 1) };
             float tyVals[2] = { (float)(st->bevLo[1] - 32 - 1), (float)(st->bevHi[1] - 32 + 1) };
+            float tzVals[2] = { (float)(first - 1), (float)calcPassive };
             maxP = v3(-1.0f, -1.0f, -1.0f); minP = v3(100000.0f, 100000.0f, 100000.0f);
             for (int zi = 0; zi < 2; ++zi) for (int yi = 0; yi < 2; ++yi) for (int xi = 0; xi < 2; ++xi) {
-                Vec3 p = transformPoint(rayIdxToDoseIdx, v3(txVals[xi], tyVals[yi], zVals[zi]));
+                Vec3 p = transformPoint(rayIdxToDoseIdx, v3(txVals[xi], tyVals[yi], tzVals[zi]));
                 if (p.x > maxP.x) maxP.x = p.x; if (p.y > maxP.y) maxP.y = p.y; if (p.z > maxP.z) maxP.z = p.z;
                 if (p.x < minP.x) minP.x = p.x; if (p.y < minP.y) minP.y = p.y; if (p.z < minP.z) minP.z = p.z;
             }
@@ -834,7 +897,7 @@ __global__ void k_ks_plan(FieldState* st, LayerPlan* layers, FieldConst fc, From
             const int hi[3] = { (int)ceilf(maxP.x) + 1, (int)ceilf(maxP.y) + 1, (int)ceilf(maxP.z) + 1 };
             for (int i = 0; i < 3; ++i) {
                 st->tboxMin[i] = lo[i] > st->bboxMin[i] ? lo[i] : st->bboxMin[i];
-                st->tboxMax[i] = hi[i] < st->bboxMax[i] ? hi[i] : st->bboxMax[i];
+                st->tboxMax[i] = hi[i] < covMax[i] ? hi[i] : covMax[i];
             }
         }
     }
@@ -900,6 +963,7 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
     const int tile = nTX * nTY <= kKsMaxOrder ? st->tileOrder[item] : item;   // busiest tiles first (k_ks_plan)
     const int tX = tile % nTX, tY = tile / nTX;
     const int first = st->beamFirstInside, calcPassive = st->firstCalculatedPassive;
+    if (st->errorFlags) return;                                      // radius overflow: the reference throws before any superposition (kernel_wrapper.cu:965)
     if (k < 0 || k < first || k >= calcPassive) return;
     if (k >= st->groupPassive[g]) return;                             // no layer of this group deposits at k: the reduce skips this partial
     const int li = lane & 15, kq = lane >> 4;                         // MFMA 16x16x4: A[i=li][k=kq], B[k=kq][j=li]
@@ -1165,6 +1229,7 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
 __global__ __launch_bounds__(256) void k_superpose_reduce(const float* __restrict__ bevPart, float* __restrict__ bevDose,
                                                            const FieldState* __restrict__ st, FieldConst fc, int G) {
     const int first = st->beamFirstInside, calcPassive = st->firstCalculatedPassive;
+    if (st->errorFlags) return;
     const size_t P = (size_t)fc.bevW * fc.bevH;
     const size_t n4 = (size_t)(calcPassive > first ? calcPassive - first : 0) * P / 4;   // P is a multiple of 4 (bevW % 32 == 0)
     const float4* p0 = reinterpret_cast<const float4*>(bevPart + (size_t)first * P);
@@ -1195,21 +1260,25 @@ __global__ __launch_bounds__(256) void k_superpose_reduce(const float* __restric
 // into a 3-D texture first (:1107-1141); here the trilinear BORDER sample is taken from the BEV buffer itself
 // (slab origin and extent applied in index arithmetic), which removes that copy. One thread per dose (x,y)
 // column and z-chunk inside the device-side bounding box (getFanIdx(z) is closed-form, so z splits freely).
+struct ClipBox { int lo[3], hi[3]; };          // inclusive dose-index box a transfer / clear is restricted to (a GPU's slab of the volume)
+
 __global__ __launch_bounds__(256) void k_transfer(float* __restrict__ dose, int nx, int ny, int nz,
                                                    const float* __restrict__ bevDose, const FieldState* __restrict__ st,
-                                                   FieldConst fc, int zChunk) {
+                                                   FieldConst fc, int zChunk, ClipBox clip) {
     const int first = st->beamFirstInside;
     const int slabZ = st->firstCalculatedPassive - first;
-    if (slabZ <= 0) return;
+    if (slabZ <= 0 || st->errorFlags) return;                        // on a device-side error the dose volume stays untouched
     // The box that can receive dose is known on the device only: a fixed grid of blocks strides over its 32 x 8 x zChunk
     // bricks (a grid over the whole dose volume would be mostly blocks that load the box and exit — measured 55 of 137 us).
-    const int bx0 = st->tboxMin[0], by0 = st->tboxMin[1], bz0 = st->tboxMin[2];
-    const int bx1 = st->tboxMax[0], by1 = st->tboxMax[1], bz1 = st->tboxMax[2];
+    const int bx0 = max(st->tboxMin[0], clip.lo[0]), by0 = max(st->tboxMin[1], clip.lo[1]), bz0 = max(st->tboxMin[2], clip.lo[2]);
+    const int bx1 = min(st->tboxMax[0], clip.hi[0]), by1 = min(st->tboxMax[1], clip.hi[1]), bz1 = min(st->tboxMax[2], clip.hi[2]);
     if (bx1 < bx0 || by1 < by0 || bz1 < bz0) return;
     const int nbx = (bx1 - bx0) / 32 + 1, nby = (by1 - by0) / 8 + 1, nbz = (bz1 - bz0) / zChunk + 1;
     const int nBricks = nbx * nby * nbz;
     const TransferParams p0 = st->transfer;
-    const float* slab = bevDose + (size_t)first * fc.bevW * fc.bevH;
+    const int pW = st->packW, pH = st->packH;
+    const float pX0 = (float)st->packX0, pY0 = (float)st->packY0;    // (subtracting an integer below the coordinate is exact)
+    const float* slab = bevDose + (size_t)st->slabFirst * pW * pH;
     // outside this rectangle (+1 for the interpolation neighbours) every BEV slice is exactly zero: no loads needed
     const float exLo = (float)(st->bevLo[0] - 1), exHi = (float)(st->bevHi[0] + 1), eyLo = (float)(st->bevLo[1] - 1), eyHi = (float)(st->bevHi[1] + 1);
     const size_t nxy = (size_t)nx * ny;
@@ -1236,7 +1305,7 @@ __global__ __launch_bounds__(256) void k_transfer(float* __restrict__ dose, int 
                 if (z + u <= z1) {
                     Vec3 pos = p.getFanIdx(z + u);
                     if (pos.x > exLo && pos.x < exHi && pos.y > eyLo && pos.y < eyHi)
-                        tmp[u] = sample3dBorder(slab, fc.bevW, fc.bevH, slabZ, pos.x, pos.y, pos.z);
+                        tmp[u] = sample3dBorder(slab, pW, pH, slabZ, pos.x - pX0, pos.y - pY0, pos.z);
                 }
             }
 #pragma unroll
@@ -1254,20 +1323,22 @@ __global__ __launch_bounds__(256) void k_transfer(float* __restrict__ dose, int 
 template <int B>
 __global__ __launch_bounds__(256) void k_transfer_t(float* __restrict__ dose, int nx, int ny, int nz,
                                                      const float* __restrict__ bevDose, const FieldState* __restrict__ st,
-                                                     FieldConst fc, int cChunk) {
+                                                     FieldConst fc, int cChunk, ClipBox clip) {
     constexpr int C = B == 1 ? 2 : 1;                                // the axis a thread walks
     constexpr int kZU = 4;
     __shared__ float tile[2][kZU][16][17];
     const int first = st->beamFirstInside;
     const int slabZ = st->firstCalculatedPassive - first;
-    if (slabZ <= 0) return;
-    const int lo[3] = {st->tboxMin[0], st->tboxMin[1], st->tboxMin[2]};
-    const int hi[3] = {st->tboxMax[0], st->tboxMax[1], st->tboxMax[2]};
+    if (slabZ <= 0 || st->errorFlags) return;                        // on a device-side error the dose volume stays untouched
+    const int lo[3] = {max(st->tboxMin[0], clip.lo[0]), max(st->tboxMin[1], clip.lo[1]), max(st->tboxMin[2], clip.lo[2])};
+    const int hi[3] = {min(st->tboxMax[0], clip.hi[0]), min(st->tboxMax[1], clip.hi[1]), min(st->tboxMax[2], clip.hi[2])};
     if (hi[0] < lo[0] || hi[1] < lo[1] || hi[2] < lo[2]) return;
     const int nbx = (hi[0] - lo[0]) / 16 + 1, nbb = (hi[B] - lo[B]) / 16 + 1, nbc = (hi[C] - lo[C]) / cChunk + 1;
     const int nBricks = nbx * nbb * nbc;
     const TransferParams p0 = st->transfer;
-    const float* slab = bevDose + (size_t)first * fc.bevW * fc.bevH;
+    const int pW = st->packW, pH = st->packH;
+    const float pX0 = (float)st->packX0, pY0 = (float)st->packY0;
+    const float* slab = bevDose + (size_t)st->slabFirst * pW * pH;
     const float exLo = (float)(st->bevLo[0] - 1), exHi = (float)(st->bevHi[0] + 1), eyLo = (float)(st->bevLo[1] - 1), eyHi = (float)(st->bevHi[1] + 1);
     const size_t nxy = (size_t)nx * ny;
     const size_t strideB = B == 1 ? (size_t)nx : nxy, strideC = C == 1 ? (size_t)nx : nxy;
@@ -1296,7 +1367,7 @@ __global__ __launch_bounds__(256) void k_transfer_t(float* __restrict__ dose, in
                     if (B == 2) { TransferParams q = p0; q.init(xg, c + u); pos = q.getFanIdx(bg); }
                     else pos = p.getFanIdx(c + u);
                     if (pos.x > exLo && pos.x < exHi && pos.y > eyLo && pos.y < eyHi)
-                        v = sample3dBorder(slab, fc.bevW, fc.bevH, slabZ, pos.x, pos.y, pos.z);
+                        v = sample3dBorder(slab, pW, pH, slabZ, pos.x - pX0, pos.y - pY0, pos.z);
                 }
                 tile[buf][u][gB][gX] = v;
             }
@@ -1313,9 +1384,10 @@ __global__ __launch_bounds__(256) void k_transfer_t(float* __restrict__ dose, in
 }
 
 // Zeroes the bricks of the dose box of the last transfer (rtd_field_clear_dose): same brick walk as k_transfer.
-__global__ __launch_bounds__(256) void k_clear_box(float* __restrict__ dose, int nx, int ny, const FieldState* __restrict__ st, int zChunk) {
-    const int bx0 = st->tboxMin[0], by0 = st->tboxMin[1], bz0 = st->tboxMin[2];
-    const int bx1 = st->tboxMax[0], by1 = st->tboxMax[1], bz1 = st->tboxMax[2];
+__global__ __launch_bounds__(256) void k_clear_box(float* __restrict__ dose, int nx, int ny, const FieldState* __restrict__ st, int zChunk,
+                                                    ClipBox clip) {
+    const int bx0 = max(st->tboxMin[0], clip.lo[0]), by0 = max(st->tboxMin[1], clip.lo[1]), bz0 = max(st->tboxMin[2], clip.lo[2]);
+    const int bx1 = min(st->tboxMax[0], clip.hi[0]), by1 = min(st->tboxMax[1], clip.hi[1]), bz1 = min(st->tboxMax[2], clip.hi[2]);
     if (bx1 < bx0 || by1 < by0 || bz1 < bz0) return;
     const int nbx = (bx1 - bx0) / 32 + 1, nby = (by1 - by0) / 8 + 1, nbz = (bz1 - bz0) / zChunk + 1;
     const size_t nxy = (size_t)nx * ny;
@@ -1326,6 +1398,39 @@ __global__ __launch_bounds__(256) void k_clear_box(float* __restrict__ dose, int
         if (x > bx1 || y > by1) continue;
         float* res = dose + (size_t)z0 * nxy + (size_t)y * nx + x;
         for (int z = z0; z <= z1; ++z, res += nxy) *res = 0.0f;
+    }
+}
+
+// Packs what another GPU needs to finish this field — the state record and the block of the BEV dose that can be non-zero
+// (rectangle [bevLo-1, bevHi+1] of the slices [entry, passive)) — into one message: [FieldState, padded to kPackHeader
+// bytes][slices x rows x columns]. The receiver runs k_transfer / k_transfer_t straight on the message (the header IS its
+// state record, with the slab geometry rewritten), restricted to its own slab of the dose volume. The BEV block of a 512^3 field
+// is ~10 MB against 60-83 MB for the dose box it turns into: the exchange of a multi-GPU plan is done in beam's-eye view.
+constexpr int kPackHeader = 2048;
+static_assert(sizeof(FieldState) <= kPackHeader, "the state record must fit the message header");
+__global__ __launch_bounds__(256) void k_pack_bev(const float* __restrict__ bevDose, const FieldState* __restrict__ st, FieldConst fc,
+                                                   unsigned char* __restrict__ msg, size_t capacity) {
+    const int first = st->beamFirstInside, nz = max(st->firstCalculatedPassive - first, 0);
+    const int x0 = max(st->bevLo[0] - 1, 0) & ~3, x1 = min(st->bevHi[0] + 1, fc.bevW - 1);     // columns in whole float4 (bevW % 32 == 0)
+    const int y0 = max(st->bevLo[1] - 1, 0), y1 = min(st->bevHi[1] + 1, fc.bevH - 1);
+    const bool none = nz == 0 || x1 < x0 || y1 < y0;
+    const int w4 = none ? 0 : (x1 - x0 + 4) / 4, h = none ? 0 : y1 - y0 + 1;
+    const size_t need = (size_t)kPackHeader + (size_t)nz * h * w4 * 16;
+    const bool fits = need <= capacity;
+    FieldState* hd = reinterpret_cast<FieldState*>(msg);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        FieldState s = *st;
+        s.packX0 = x0; s.packY0 = y0; s.packW = 4 * w4; s.packH = h; s.slabFirst = 0;
+        if (none) { s.tboxMin[0] = 0; s.tboxMax[0] = -1; }
+        if (!fits) s.errorFlags |= kErrPackOverflow;                 // the receiver's transfer then leaves the dose untouched
+        *hd = s;
+    }
+    if (!fits || none) return;
+    float4* dst = reinterpret_cast<float4*>(msg + kPackHeader);
+    const size_t P = (size_t)fc.bevW * fc.bevH, n4 = (size_t)nz * h * w4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % w4), r = (int)((i / w4) % h), k = (int)(i / ((size_t)w4 * h));
+        dst[i] = *reinterpret_cast<const float4*>(bevDose + (size_t)(first + k) * P + (size_t)(y0 + r) * fc.bevW + x0 + 4 * c);
     }
 }
 

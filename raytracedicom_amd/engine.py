@@ -63,6 +63,16 @@ def lib():
         L.rtd_field_clear_dose.argtypes = [vp, vp, vp]
         L.rtd_field_destroy.argtypes = [vp, vp]
         L.rtd_field_fetch.argtypes = [vp, vp, C.c_char_p, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+        i3 = C.POINTER(C.c_int32)
+        L.rtd_field_compute_bev.argtypes = [vp, vp]
+        L.rtd_field_transfer.argtypes = [vp, vp, vp, i3, i3]
+        L.rtd_field_wait_plan.argtypes = [vp, vp, C.POINTER(abi.RtdFieldInfo), C.POINTER(C.c_size_t)]
+        L.rtd_bev_message_bound.argtypes = [vp, vp]
+        L.rtd_bev_message_bound.restype = C.c_size_t
+        L.rtd_field_export_bev.argtypes = [vp, vp, vp, C.c_size_t]
+        L.rtd_field_create_remote.argtypes = [vp, C.POINTER(abi.RtdBeam), u3, vpp]
+        L.rtd_field_attach_bev.argtypes = [vp, vp, vp]
+        L.rtd_field_clear_dose_box.argtypes = [vp, vp, vp, i3, i3]
         L.rtd_device_alloc.argtypes = [vp, C.c_size_t, vpp]
         L.rtd_device_free.argtypes = [vp, vp]
         L.rtd_device_zero.argtypes = [vp, vp, C.c_size_t]
@@ -79,13 +89,54 @@ def lib():
 class Field:
     """One beam prepared on the device (rtd_field_*)."""
 
-    def __init__(self, eng, beam, dose_dims):
+    def __init__(self, eng, beam, dose_dims, remote=False):
         self.eng = eng
         self._beam = beam            # keeps the numpy arrays alive
         self._h = C.c_void_p()
         ba = beam.as_abi()
-        eng._check(lib().rtd_field_create(eng._h, C.byref(ba), abi.uint3(dose_dims), C.byref(self._h)))
+        create = lib().rtd_field_create_remote if remote else lib().rtd_field_create
+        eng._check(create(eng._h, C.byref(ba), abi.uint3(dose_dims), C.byref(self._h)))
+        self.remote = remote
         self.computed = False        # a compute() has been launched (clear_dose / finish are valid)
+
+    @staticmethod
+    def _clip(lo, hi):
+        if lo is None:
+            return None, None
+        return (C.c_int32 * 3)(*[int(v) for v in lo]), (C.c_int32 * 3)(*[int(v) for v in hi])
+
+    def compute_bev(self):
+        """All kernels up to the beam's-eye-view dose; asynchronous."""
+        self.eng._check(lib().rtd_field_compute_bev(self.eng._h, self._h))
+        self.computed = True
+
+    def transfer(self, dev_dose, clip_min=None, clip_max=None):
+        """Fan -> dose-grid transfer of the field's BEV dose (its own or an attached slab) into dev_dose, optionally restricted
+        to the inclusive dose-index box [clip_min, clip_max]; asynchronous."""
+        lo, hi = self._clip(clip_min, clip_max)
+        self.eng._check(lib().rtd_field_transfer(self.eng._h, self._h, C.c_void_p(int(dev_dose)), lo, hi))
+
+    def wait_plan(self):
+        """(info, packed_bytes) once the device-side plan of the field is known (the superposition may still be running)."""
+        i, n = abi.RtdFieldInfo(), C.c_size_t(0)
+        self.eng._check(lib().rtd_field_wait_plan(self.eng._h, self._h, C.byref(i), C.byref(n)))
+        return i.as_dict(), int(n.value)
+
+    def message_bound(self):
+        return int(lib().rtd_bev_message_bound(self.eng._h, self._h))
+
+    def export_bev(self, dev_buf, capacity):
+        """Pack [state record | non-zero block of the BEV dose] into dev_buf (device pointer); asynchronous."""
+        self.eng._check(lib().rtd_field_export_bev(self.eng._h, self._h, C.c_void_p(int(dev_buf)), int(capacity)))
+
+    def attach_bev(self, dev_buf):
+        """Remote field: sample the message at dev_buf (device pointer; not copied)."""
+        self.eng._check(lib().rtd_field_attach_bev(self.eng._h, self._h, C.c_void_p(int(dev_buf))))
+        self.computed = True
+
+    def clear_dose_box(self, dev_dose, clip_min=None, clip_max=None):
+        lo, hi = self._clip(clip_min, clip_max)
+        self.eng._check(lib().rtd_field_clear_dose_box(self.eng._h, self._h, C.c_void_p(int(dev_dose)), lo, hi))
 
     def compute(self, dev_dose):
         """Launch all kernels of the field; asynchronous. dev_dose: device pointer (int) of the dose volume."""
@@ -171,8 +222,8 @@ class Engine:
         self._check(lib().rtd_compute(self._h, ba, len(beams), abi.fptr(dose), abi.uint3((dose.shape[2], dose.shape[1], dose.shape[0])), tm))
         return [tm[i].as_dict() for i in range(len(beams))]
 
-    def create_field(self, beam, dose_dims):
-        return Field(self, beam, dose_dims)
+    def create_field(self, beam, dose_dims, remote=False):
+        return Field(self, beam, dose_dims, remote=remote)
 
     # device buffers owned by the handle
     def device_alloc(self, nbytes):

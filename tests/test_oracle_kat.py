@@ -204,3 +204,20 @@ def test_expected_deviation_of_a_texture_hardware_run(orc, synth):
     print("tex8 vs exact: gamma pass %.4f over %d voxels, gamma max %.3f, max rel diff above 10%% = %.3g" % (rate, n_eval, gmax, rel))
     assert rate >= 0.99
     assert 1e-5 < rel < 0.2          # visibly different from float-exact, far from gamma failure
+
+
+def test_deterministic_power_matches_a_double_precision_pow(orc):
+    """rtd_pow_det (include/rtd_detmath.h) stands in for the reference's __powf (kernel_wrapper.cu:282) in the oracle AND in the
+    engine, so that the radius classes can be compared bit for bit. Pinned here against a double-precision pow over the
+    argument range of the sigma recurrence (residual range 1e-6 .. 400 mm, exponent 0.5649718): <= 2.7e-7 relative."""
+    import ctypes as C
+    L = orc.lib()
+    L.orc_pow_det.restype = C.c_float
+    L.orc_pow_det.argtypes = [C.c_float, C.c_float]
+    rng = np.random.default_rng(5)
+    xs = np.exp(rng.uniform(np.log(1e-6), np.log(400.0), 20000)).astype(np.float32)
+    xs = np.concatenate([xs, np.float32([1.0, 2.0, 0.5, 0.70710678, 0.7071068, 1.4142135, 100.799, 3.0e-6, 399.9])])
+    y = np.float32(0.5649718)
+    got = np.array([L.orc_pow_det(float(x), float(y)) for x in xs], dtype=np.float64)
+    ref = np.power(xs.astype(np.float64), np.float64(y))
+    assert (np.abs(got - ref) / ref).max() < 2.7e-7
