@@ -95,6 +95,14 @@ class RtdFieldInfo(C.Structure):
         return out
 
 
+class RtdPlanTiming(C.Structure):
+    _fields_ = [("total_ms", C.c_float), ("upload_ms", C.c_float), ("bev_ms", C.c_float), ("exchange_ms", C.c_float),
+                ("transfer_ms", C.c_float), ("download_ms", C.c_float), ("n_devices", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
 def default_options():
     """Reference defaults of the compile-time switches (CMakeLists.txt:36-79)."""
     o = RtdOptions()

@@ -73,6 +73,19 @@ def lib():
         L.rtd_field_create_remote.argtypes = [vp, C.POINTER(abi.RtdBeam), u3, vpp]
         L.rtd_field_attach_bev.argtypes = [vp, vp, vp]
         L.rtd_field_clear_dose_box.argtypes = [vp, vp, vp, i3, i3]
+        L.rtd_field_release.argtypes = [vp, vp]
+        L.rtd_host_register.argtypes = [vp, C.c_size_t]
+        L.rtd_host_unregister.argtypes = [vp]
+        L.rtd_plan_create.argtypes = [C.POINTER(C.c_int), C.c_int, vpp]
+        L.rtd_plan_destroy.argtypes = [vp]
+        L.rtd_plan_last_error.argtypes = [vp]
+        L.rtd_plan_last_error.restype = C.c_char_p
+        L.rtd_plan_set_options.argtypes = [vp, C.POINTER(abi.RtdOptions)]
+        L.rtd_plan_set_luts.argtypes = [vp, C.POINTER(abi.RtdLuts)]
+        L.rtd_plan_load_luts_dir.argtypes = [vp, C.c_char_p, C.c_int]
+        L.rtd_plan_set_ct.argtypes = [vp, abi.c_float_p, u3]
+        L.rtd_plan_compute.argtypes = [vp, C.POINTER(abi.RtdBeam), C.c_int, abi.c_float_p, u3, C.POINTER(abi.RtdTiming),
+                                       C.POINTER(abi.RtdPlanTiming)]
         L.rtd_device_alloc.argtypes = [vp, C.c_size_t, vpp]
         L.rtd_device_free.argtypes = [vp, vp]
         L.rtd_device_zero.argtypes = [vp, vp, C.c_size_t]
@@ -164,6 +177,12 @@ class Field:
             lib().rtd_field_destroy(self.eng._h, self._h)
             self._h = C.c_void_p()
 
+    def release(self):
+        """Like destroy(), but the device workspace stays with the engine for the next field of the same shape."""
+        if self._h:
+            lib().rtd_field_release(self.eng._h, self._h)
+            self._h = C.c_void_p()
+
     def __del__(self):
         try:
             self.destroy()
@@ -253,6 +272,65 @@ class Engine:
 
     def set_stream(self, s):
         self._check(lib().rtd_set_stream(self._h, C.c_void_p(s) if s else None))
+
+
+class Plan:
+    """rtd_plan_*: the reference-shaped call on several GPUs of one process (one host thread per device)."""
+
+    def __init__(self, device_ids):
+        self._h = C.c_void_p()
+        ids = (C.c_int * len(device_ids))(*[int(d) for d in device_ids])
+        st = lib().rtd_plan_create(ids, len(device_ids), C.byref(self._h))
+        if st != 0:
+            raise RtdError(st, lib().rtd_global_error().decode())
+
+    def _check(self, st):
+        if st != 0:
+            raise RtdError(st, lib().rtd_plan_last_error(self._h).decode())
+
+    def close(self):
+        if self._h:
+            lib().rtd_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_options(self, opt):
+        self._check(lib().rtd_plan_set_options(self._h, C.byref(opt)))
+
+    def set_luts(self, es):
+        la = es.as_abi()
+        self._check(lib().rtd_plan_set_luts(self._h, C.byref(la)))
+
+    def set_ct(self, ct):
+        ct = abi.f32(ct)
+        self._check(lib().rtd_plan_set_ct(self._h, abi.fptr(ct), abi.uint3((ct.shape[2], ct.shape[1], ct.shape[0]))))
+
+    def compute(self, beams, dose):
+        """All beams accumulated into the host array dose ([Z][Y][X] float32); returns (per-beam timings, plan timing)."""
+        from .scenarios import beams_abi
+        assert dose.dtype == np.float32 and dose.flags["C_CONTIGUOUS"]
+        ba = beams_abi(beams)
+        tm = (abi.RtdTiming * max(1, len(beams)))()
+        pt = abi.RtdPlanTiming()
+        self._check(lib().rtd_plan_compute(self._h, ba, len(beams), abi.fptr(dose), abi.uint3((dose.shape[2], dose.shape[1], dose.shape[0])), tm,
+                                           C.byref(pt)))
+        return [tm[i].as_dict() for i in range(len(beams))], pt.as_dict()
+
+
+def host_register(arr):
+    """Page-lock a numpy array (HostPinnedImage3D's cudaHostRegister, host_image_3d.cuh:23-32)."""
+    st = lib().rtd_host_register(arr.ctypes.data_as(C.c_void_p), arr.nbytes)
+    if st != 0:
+        raise RtdError(st, lib().rtd_global_error().decode())
+
+
+def host_unregister(arr):
+    lib().rtd_host_unregister(arr.ctypes.data_as(C.c_void_p))
 
 
 def cudaWrapperProtons(imVol, doseVol, beams, iddData, outStream=None, device_id=0, options=None):

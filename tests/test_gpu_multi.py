@@ -1,0 +1,200 @@
+"""GPU tests of the pieces a multi-GPU plan is made of (all through the C ABI, on ONE GPU): the two halves of a field,
+the exported BEV slab and the clipped transfers, and the in-process plan (rtd_plan_*) driven with several handles on the
+same device. Bit-identity with the sequential single-GPU call is the bar: every voxel receives the same `+=` sequence."""
+import math
+
+import numpy as np
+import pytest
+
+from raytracedicom_amd import abi, scenarios
+
+pytestmark = pytest.mark.gpu
+
+
+def _scn(synth, n=128, angles=(0.0, 90.0, 37.0), dist=(math.inf, math.inf)):
+    ct, _ = scenarios.hetero_phantom(n)
+    return scenarios.hetero_ct(synth, n=n, spots=6, pitch=7.0, n_layers=4, angles=list(angles), source_dist=dist, ct=ct)
+
+
+def _sequential(engine, scn, base=None):
+    dose = np.zeros_like(scn.ct) if base is None else base.copy()
+    with engine.Engine(0) as eng:
+        eng.set_luts(scn.luts)
+        eng.set_ct(scn.ct)
+        eng.compute(scn.beams, dose)
+    return dose
+
+
+def test_bev_then_transfer_equals_compute(engine, synth):
+    """rtd_field_compute == rtd_field_compute_bev + rtd_field_transfer; clipped transfers into disjoint boxes add up to it."""
+    scn = _scn(synth, angles=(30.0,))
+    n = scn.n_voxels
+    with engine.Engine(0) as eng:
+        eng.set_luts(scn.luts)
+        eng.set_ct(scn.ct)
+        f = eng.create_field(scn.beams[0], scn.dims)
+        d = [eng.device_alloc(4 * n) for _ in range(3)]
+        for p in d:
+            eng.device_zero(p, 4 * n)
+        f.compute(d[0])
+        f.finish()
+        f.compute_bev()
+        f.transfer(d[1])
+        nz = scn.dims[2]
+        cuts = [0, nz // 3, nz // 2, nz]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            f.transfer(d[2], (0, 0, a), (scn.dims[0] - 1, scn.dims[1] - 1, b - 1))
+        t, info = f.finish()
+        out = [np.empty_like(scn.ct) for _ in range(3)]
+        for o, p in zip(out, d):
+            eng.to_host(o, p)
+        assert out[0].max() > 0 and t["transforming_ms"] >= 0
+        np.testing.assert_array_equal(out[1], out[0])
+        np.testing.assert_array_equal(out[2], out[0])
+        # clear of a clipped box: zero inside, untouched outside
+        f.clear_dose_box(d[0], (0, 0, 0), (scn.dims[0] - 1, scn.dims[1] - 1, nz // 2 - 1))
+        eng.to_host(out[1], d[0])
+        assert out[1][:nz // 2].max() == 0.0
+        np.testing.assert_array_equal(out[1][nz // 2:], out[0][nz // 2:])
+        f.destroy()
+        for p in d:
+            eng.device_free(p)
+
+
+@pytest.mark.parametrize("deg,dist", [(0.0, (math.inf, math.inf)), (90.0, (1800.0, 2200.0)), (141.0, (math.inf, math.inf))])
+def test_exported_bev_slab_transfers_identically_on_another_handle(engine, synth, deg, dist):
+    """The message [state record | non-zero block of the BEV dose] attached to a geometry-only field on ANOTHER handle gives the
+    same dose bits as the field's own transfer (plain and transposed transfer kernels, divergent beam)."""
+    scn = _scn(synth, angles=(deg,), dist=dist)
+    n = scn.n_voxels
+    a, b = engine.Engine(0), engine.Engine(0)
+    try:
+        a.set_luts(scn.luts)
+        a.set_ct(scn.ct)
+        f = a.create_field(scn.beams[0], scn.dims)
+        da = a.device_alloc(4 * n)
+        a.device_zero(da, 4 * n)
+        f.compute(da)
+        info, nbytes = f.wait_plan()
+        assert 2048 < nbytes <= f.message_bound()
+        msg = a.device_alloc(nbytes)
+        f.export_bev(msg, nbytes)
+        f.finish()
+        a.sync()
+        # (how the slab compares with the dose box it turns into depends on voxel size against ray spacing: 2 mm voxels here
+        #  make the box the smaller one; on the 0.5 mm grid of the bench workload the slab is 6-8 times smaller)
+        r = b.create_field(scn.beams[0], scn.dims, remote=True)         # needs neither LUTs nor CT on handle b
+        db = b.device_alloc(4 * n)
+        b.device_zero(db, 4 * n)
+        r.attach_bev(msg)
+        r.transfer(db)
+        _, rinfo = r.finish()
+        assert rinfo["dose_box_min"] == info["dose_box_min"] and rinfo["dose_box_max"] == info["dose_box_max"]
+        x, y = np.empty_like(scn.ct), np.empty_like(scn.ct)
+        a.to_host(x, da)
+        b.to_host(y, db)
+        assert x.max() > 0
+        np.testing.assert_array_equal(y, x)
+        # a message buffer that is too small is reported, and the receiver's volume stays untouched
+        small = a.device_alloc(4096)
+        f.export_bev(small, 4096)
+        a.sync()
+        b.device_zero(db, 4 * n)
+        r.attach_bev(small)
+        r.transfer(db)
+        with pytest.raises(engine.RtdError):
+            r.finish()
+        b.to_host(y, db)
+        assert y.max() == 0.0
+        r.destroy(); f.destroy()
+        for e, p in ((a, da), (a, msg), (a, small), (b, db)):
+            e.device_free(p)
+    finally:
+        a.close(); b.close()
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
+def test_in_process_plan_equals_sequential_call(orc, engine, synth, devices):
+    """rtd_plan_compute with 1, 2 and 3 handles (threads) on one GPU: bit-identical to rtd_compute on one handle — incoming dose
+    kept, beams dealt round-robin, BEV slabs exchanged, every handle transferring all beams into its z-slab — and equal to the
+    oracle within the dose tolerance."""
+    scn = _scn(synth, angles=(0.0, 90.0, 37.0, 180.0))
+    base = np.full_like(scn.ct, 1e-7)
+    want = _sequential(engine, scn, base)
+    dose = base.copy()
+    with engine.Plan(devices) as plan:
+        plan.set_luts(scn.luts)
+        plan.set_ct(scn.ct)
+        per_beam, pt = plan.compute(scn.beams, dose)
+        assert pt["n_devices"] == len(devices) and pt["total_ms"] > 0 and len(per_beam) == 4
+        np.testing.assert_array_equal(dose, want)
+        # second call on the same plan object (workspaces and message buffers are reused)
+        dose2 = base.copy()
+        plan.compute(scn.beams, dose2)
+        np.testing.assert_array_equal(dose2, want)
+    ref = orc.compute(scn, dose=base.copy())
+    mx = float(ref.max())
+    assert np.abs(dose - ref).max() <= 1e-4 * mx
+    rate, n_eval, _ = orc.gamma_pass_rate(ref, dose, scn.spacing)
+    assert rate == 1.0 and n_eval > 0
+
+
+def test_in_process_plan_reports_device_side_errors_and_keeps_the_volume(engine, synth):
+    """A beam whose superposition radius overflows fails the whole plan call (kernel_wrapper.cu:965) and the caller's dose
+    buffer is left as it was."""
+    scn = scenarios.water_cube(synth, n=32, n_layers=1, spots=3)
+    good = scn.beams[0]
+    bad = scenarios.make_field(synth, 32, 8.0, (-128.0, -128.0, -106.0), 0.0, 3, 1.0, 1, 5, ray_spacing=(0.05, 0.05), steps=256, weight_lo=1e5)
+    dose = np.full_like(scn.ct, 0.25)
+    with engine.Plan([0, 0]) as plan:
+        plan.set_luts(scn.luts)
+        plan.set_ct(scn.ct)
+        with pytest.raises(engine.RtdError) as e:
+            plan.compute([good, bad], dose)
+        assert e.value.status == abi.RTD_ERR_RADIUS_OVERFLOW
+    assert (dose == 0.25).all()
+
+
+def test_radius_overflow_leaves_the_device_volume_untouched(engine, synth):
+    """The split form: on a radius overflow neither the superposition nor the transfer runs, so dev_dose keeps its contents
+    (the reference throws before any superposition launch, kernel_wrapper.cu:965)."""
+    scn = scenarios.water_cube(synth, n=32, n_layers=1, spots=3)
+    bad = scenarios.make_field(synth, 32, 8.0, (-128.0, -128.0, -106.0), 0.0, 3, 1.0, 1, 5, ray_spacing=(0.05, 0.05), steps=256, weight_lo=1e5)
+    with engine.Engine(0) as eng:
+        eng.set_luts(scn.luts)
+        eng.set_ct(scn.ct)
+        n = scn.n_voxels
+        d = eng.device_alloc(4 * n)
+        init = np.full_like(scn.ct, 3.0)
+        eng.to_device(d, init)
+        f = eng.create_field(bad, scn.dims)
+        f.compute(d)
+        with pytest.raises(engine.RtdError) as e:
+            f.finish()
+        assert e.value.status == abi.RTD_ERR_RADIUS_OVERFLOW
+        out = np.empty_like(scn.ct)
+        eng.to_host(out, d)
+        np.testing.assert_array_equal(out, init)
+        f.destroy()
+        eng.device_free(d)
+
+
+def test_released_workspace_is_taken_over(engine, synth):
+    """rtd_field_release + rtd_field_create of the same shape reuses the device workspace; results are those of fresh fields."""
+    scn = _scn(synth, angles=(0.0, 180.0))
+    want = _sequential(engine, scn)
+    n = scn.n_voxels
+    with engine.Engine(0) as eng:
+        eng.set_luts(scn.luts)
+        eng.set_ct(scn.ct)
+        d = eng.device_alloc(4 * n)
+        eng.device_zero(d, 4 * n)
+        for beam in scn.beams:
+            f = eng.create_field(beam, scn.dims)
+            f.compute(d)
+            f.finish()
+            f.release()
+        out = np.empty_like(scn.ct)
+        eng.to_host(out, d)
+        np.testing.assert_array_equal(out, want)
+        eng.device_free(d)
