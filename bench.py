@@ -2,16 +2,20 @@
 """bench.py — headline benchmark of the MI355X dose engine (BASELINE.json metric).
 
 metric   Mvoxels/s of dose deposited: dose-grid voxels x fields / wall time of the plan, inputs (CT, LUTs, spot
-         weights, workspace) already resident in HBM; the dose volume is zeroed inside the timed step.
+         weights, workspace) already resident in HBM; the dose volume is restored to zero inside the timed step.
 workload N=1: C3 = 512^3 synthetic heterogeneous CT, one field, 10x10 spots x 20 energy layers, 512 tracer steps
-         (SURVEY.md §8d, BASELINE.json configs[2] — the configuration the metric is quoted on).
-         N>1: one field per GPU (gantry angles 360/N apart, same CT replicated), per-rank dose volumes summed into
-         rank 0 with one RCCL reduce inside the timed step (weak scaling: per-GPU work fixed).
-step     = zero the dose volume + rtd_field_compute (all kernels of the field) + rtd_field_finish (sync)
-         [+ N>1: reduce of the union of the fields' bounding boxes into rank 0].
+         (SURVEY.md 8(d), BASELINE.json configs[2] — the configuration the metric is quoted on).
+         N>1: one field per GPU (gantry angles 360/N apart, same CT replicated): weak scaling, per-GPU work fixed.
+step     N=1: restore the zero dose volume + all kernels of the field + rtd_field_finish (pipelined by one plan).
+         N>1: every rank computes its field up to the beam's-eye-view (BEV) dose, ONE RCCL all-gather moves the packed BEV
+         slabs (~10 MB each; the dose boxes they turn into are 60-83 MB), and every rank runs the fan -> dose transfer of EVERY
+         field, in field order, into its own slab of the dose volume (plan.BevExchange). The plan's volume is left sharded by
+         slabs across the GPUs; it is bit-identical to the sequential one-GPU accumulation of the N fields.
 
-One JSON line on rank 0; `roofline` describes the dominant kernel (kernel superposition) from HIP events recorded
-by the engine on the launch stream during the timed steps; `cpu_baseline` is the CPU oracle timed on this host.
+One JSON line on rank 0; `roofline` describes the dominant kernel (kernel superposition) from the kernels' own dispatch
+timestamps taken by the engine on the launch stream during the timed steps; `cpu_baseline` is the CPU oracle timed on this host.
+Also reported: `ms_plan_latency` (ONE plan, nothing to pipeline against) and, at N=1, `ms_plan_end_to_end` (the reference's
+"total global execution time": CT + LUT upload, dose up, all kernels, dose down, from page-locked host buffers).
 
 Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--size 512] [--no-cpu]
        N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -28,13 +32,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, Chip-level parameters)
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md, Chip-level parameters)
+F32_MATRIX_PEAK_TF = 157.3   # v_mfma_f32_16x16x4_f32 peak = f32 vector peak (MI355X_MICROARCH.md, Matrix cores)
 
 
-def algorithmic_bytes(info, dims):
-    """Algorithmic HBM bytes of one field, per stage (SURVEY.md §8d formula; fp32).
-    R rays, S steps, P padded BEV slice, SA = sum over layers of live steps, V_bb = dose voxels in the bounding box.
-    The tracer's CT term uses the ray-grid footprint bound min(N, 8*R*S) (distinct voxels touched <= samples*8)."""
+def algorithmic_bytes(info, dims, ct_footprint):
+    """Algorithmic HBM bytes of one field, per stage (SURVEY.md 8(d) formula; fp32).
+    R rays, S steps, P padded BEV slice, SA = sum over layers of live steps, V_bb = dose voxels in the bounding box, N_fp = distinct
+    CT voxels the tracer reads (counted by the oracle; without the oracle leg the bound min(N, 8*R*S))."""
     W, H, L = info["ray_dims"]
     R, P = W * H, (W + 64) * (H + 64)
     S = info["_steps"]
@@ -43,15 +48,26 @@ def algorithmic_bytes(info, dims):
     bb = [max(0, info["bbox_max"][i] - info["bbox_min"][i] + 1) for i in range(3)]
     vbb = bb[0] * bb[1] * bb[2]
     n = dims[0] * dims[1] * dims[2]
+    nfp = ct_footprint if ct_footprint is not None else min(n, 8 * R * S)
     out = {
-        "tracer": 4 * min(n, info.get("_ct_footprint", 8 * R * S)) + 8 * R * S + 8 * R + 4 * R * S,   # CT + density,WEPL + 2 int maps + min-WEPL read
-        "fill": 16 * R * SA + 4 * R * L + 4 * R * SA,                                       # read rho,WEPL; write idd,1/sigma; weights; tile radius
-        "superposition": 8 * R * SA + 8 * P * SA,                                           # read idd,1/sigma; RMW padded BEV
+        "tracer": 4 * nfp + 8 * R * S + 8 * R + 4 * R * S,   # CT + density,WEPL + 2 int maps + min-WEPL read
+        "fill": 16 * R * SA + 4 * R * L + 4 * R * SA,        # read rho,WEPL; write idd,1/sigma; weights; tile radius
+        "superposition": 8 * R * SA + 8 * P * SA,            # read idd,1/sigma; RMW padded BEV
         "bev_zero_read": 4 * P * S + 4 * P * Z,
         "transfer": 8 * vbb,
     }
     out["total"] = sum(out.values())
     return out
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def main():
@@ -60,7 +76,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=512, help="CT edge in voxels (512 = C3/C4, 768 = C5)")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity / end-to-end legs")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--streams", type=int, default=1,
                     help="N=1 only, not the default: launch consecutive plans round-robin on this many HIP streams, so the kernels of "
@@ -75,9 +91,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" % (args.gpus, args.gpus))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the dose engine has no CPU fallback")
     dev_index = local_rank % torch.cuda.device_count()     # one GPU per rank on a real node; shared only in a gloo rehearsal
@@ -90,6 +105,10 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=args.backend)
+    # Every torch op, every engine launch and every collective of this process is issued on ONE explicit stream: torch's default
+    # stream has handle 0, which the C ABI reads as "the handle's own stream" — the engine would then run unordered against torch.
+    main_stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(main_stream)
 
     # ---- synthetic inputs (same CT on every rank; field r at gantry angle r*360/world) ----
     n = args.size
@@ -104,63 +123,61 @@ def main():
     opt = abi.default_options()
     opt.fine_grained_timing = 1
     eng.set_options(opt)
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.set_stream(main_stream.cuda_stream)
+    assert int(eng.stream() or 0) == int(main_stream.cuda_stream) != 0
     eng.set_luts(es)
     ct_dev = torch.from_numpy(ct_np).to(dev)
     eng.set_ct_device(ct_dev.data_ptr(), scn.dims)
-    # N>1: two alternating dose volumes so that the reduce of plan i (communication stream) overlaps the kernels of plan i+1
     n_streams = max(1, args.streams)
     assert n_streams == 1 or world == 1, "--streams is a one-GPU mode"
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else None
-    doses = [torch.zeros((n, n, n), dtype=torch.float32, device=dev) for _ in range(2 if world > 1 else (n_streams + 1 if n_streams > 1 else 1))]
+    n_vol = 2 if world > 1 else (n_streams + 1 if n_streams > 1 else 1)
+    doses = [torch.zeros((n, n, n), dtype=torch.float32, device=dev) for _ in range(n_vol)]
     dose = doses[0]
-    # Two field objects of the same beam alternate, so plan i+1 is launched before plan i is finished (rtd_field_finish waits
-    # for its own field's last kernel only): the device does not idle while the host reads back timing and geometry.
-    flds = [eng.create_field(beam, scn.dims) for _ in range(n_streams + 1)]
+    # Field objects of the same beam alternate, so plan i+1 is launched before plan i is finished (rtd_field_finish waits for
+    # its own field's last kernel only): the device does not idle while the host reads back timing and geometry.
+    flds = [eng.create_field(beam, scn.dims) for _ in range(2 if world > 1 else n_streams + 1)]
     fld = flds[0]
-    # N = 2: rank 1 sends its dose box straight to rank 0. N >= 3: point-to-point reduce-scatter + gather (pieces to owner slabs,
-    # complete slabs to rank 0): the links into rank 0 carry (box + union box) / N instead of a whole box each (plan.py).
-    # RTD_BENCH_REDUCE=direct|slab overrides. The fields keep their geometry: the 6-int boxes are exchanged once.
-    reduce_mode = os.environ.get("RTD_BENCH_REDUCE", "slab" if world >= 3 else "direct")
-    reducer = None
+    ex = None
     if world > 1:
-        reducer = (plan.PipelinedSlabReduce if reduce_mode == "slab" else plan.PipelinedBoxReduce)(dist, static_boxes=True)
-    torch.cuda.synchronize()
+        remote = {r: eng.create_field(scn.beams[r], scn.dims, remote=True) for r in range(world) if r != rank}
+        ex = plan.BevExchange(dist, rank, world, remote, scn.dims, new_bytes=lambda k: torch.empty(int(k), dtype=torch.uint8, device=dev))
+        fld.compute_bev()
+        ex.setup(fld)               # message capacity, dose boxes, slab partition: the fields keep their geometry
+        fld.finish()
+    main_stream.synchronize()
     step_no = [0]
-    in_flight = []                      # (field, dose volume) launched, not yet finished
+    in_flight = []                      # (step index, field) launched, not yet finished
 
     def launch():
-        """Launch one plan iteration: fresh dose volume + all kernels of this rank's field (asynchronous)."""
+        """Launch one plan iteration (asynchronous). N=1: fresh dose volume + all kernels of the field. N>1: this rank's field up to
+        its BEV dose, slab packed, all-gather started."""
         i = step_no[0]
-        d, f = doses[i % len(doses)], flds[i % len(flds)]
-        if streams is not None:
-            eng.set_stream(streams[i % n_streams].cuda_stream)
-        first_use = i < len(doses)              # the volume is still the all-zero allocation
         step_no[0] += 1
-        views = reducer.release(d) if reducer is not None else None  # the exchange that used this volume two plans ago has completed
-        # fresh dose volume: only the voxels the previous plan wrote are cleared (rtd_field_clear_dose: the field's device-side
-        # dose box; on the destination rank also the boxes that received the other ranks' dose), not all 512^3
-        if not first_use:
-            if f.computed:
+        f = flds[i % len(flds)]
+        if ex is None:
+            d = doses[i % len(doses)]
+            if streams is not None:
+                eng.set_stream(streams[i % n_streams].cuda_stream)
+            # fresh dose volume: only the voxels the previous plan wrote are cleared (rtd_field_clear_dose), not all 512^3
+            if i >= len(doses):
                 f.clear_dose(d.data_ptr())
-            else:
-                d.zero_()
-            for v in views or ():
-                v.zero_()
-        f.compute(d.data_ptr())
-        ready = torch.cuda.Event() if reducer is not None else None
-        if ready is not None:
-            ready.record(torch.cuda.current_stream())     # the exchange of this plan is ordered behind this plan only
-        in_flight.append((f, d, ready))
+            f.compute(d.data_ptr())
+        else:
+            b = i % 2
+            if i >= 2:
+                ex.clear(f, b, doses[b].data_ptr())      # what plan i-2 wrote into this volume (all fields, this rank's slab)
+            f.compute_bev()
+            ex.post(f, b)
+        in_flight.append((i, f))
 
     def retire():
-        """Finish the oldest launched plan: wait for its last kernel, per-stage hipEvent times + bounding box, [N>1: start the
-        reduce of the union bounding box into rank 0, left in flight while later plans run]."""
-        f, d, ready = in_flight.pop(0)
-        t, info = f.finish()
-        if reducer is not None:
-            reducer.submit(d, info["dose_box_min"], info["dose_box_max"], ready=ready)
-        return t, info
+        """Finish the oldest launched plan. N>1: wait (in stream order) for its all-gather and transfer every field into this rank's
+        slab first."""
+        i, f = in_flight.pop(0)
+        if ex is not None:
+            ex.complete(f, i % 2, doses[i % 2].data_ptr())
+        return f.finish()
 
     def step():
         """One plan iteration in steady state: launch plan i, then finish plan i-1 (pipelined by one)."""
@@ -170,8 +187,7 @@ def main():
         return None
 
     def barrier():
-        if reducer is not None:
-            reducer.drain()             # every plan's reduce has completed and rank 0 holds the sums
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -180,22 +196,24 @@ def main():
         step()
     while in_flight:
         retire()
-    if reducer is not None:
-        reducer.drain()
     buckets = {}
     n_timed = 0
+    info = None
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         r = step()
         if r is not None:
             for k, v in r[0].items():
-                buckets[k] = buckets.get(k, 0.0) + float(v)
+                if isinstance(v, float):
+                    buckets[k] = buckets.get(k, 0.0) + float(v)
+            info = r[1]
             n_timed += 1
     while in_flight:                    # the last plan is finished inside the timed region
         t, info = retire()
         for k, v in t.items():
-            buckets[k] = buckets.get(k, 0.0) + float(v)
+            if isinstance(v, float):
+                buckets[k] = buckets.get(k, 0.0) + float(v)
         n_timed += 1
     barrier()
     elapsed = time.perf_counter() - t0
@@ -206,53 +224,88 @@ def main():
         elapsed = float(tmax.item())
     ms_per_step = 1000.0 * elapsed / args.steps
 
-    # self-check (untimed): a volume restored by the dirty-box clear of launch() must be bit-identical to the same field
-    # computed into a fully zeroed volume (compared BEFORE this plan's exchange is submitted: under RCCL the destination's
-    # adds are queued at submit time and may already have run)
+    # ---- latency of ONE plan: nothing to pipeline against (launch, finish, drained stream), mean of 5 ----
+    lat = []
+    for _ in range(5):
+        barrier()
+        l0 = time.perf_counter()
+        launch()
+        retire()
+        torch.cuda.synchronize()
+        lat.append(time.perf_counter() - l0)
+    ms_latency = 1000.0 * sum(lat) / len(lat)
+    if world > 1:
+        tl = torch.tensor([ms_latency], dtype=torch.float64, device=dev)
+        dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+        ms_latency = float(tl.item())
+
+    # ---- self-checks (untimed) ----
+    # (a) a volume restored by the dirty-box clears of launch() is bit-identical to the same plan computed into a fully zeroed volume
     launch()
-    f_chk, last, _ = in_flight.pop(0)
-    _, chk_info0 = f_chk.finish()
+    i_chk, f_chk = in_flight[0]
+    retire()
+    last = doses[i_chk % len(doses)]
     ref = torch.zeros_like(last)
-    fld.compute(ref.data_ptr())
-    fld.finish()
+    if ex is None:
+        fld2 = flds[(i_chk + 1) % len(flds)]
+        fld2.compute(ref.data_ptr())
+        fld2.finish()
+    else:
+        ex.complete(f_chk, i_chk % 2, ref.data_ptr())      # same gathered slabs, same field order, fresh volume
+        f_chk.finish()
+    torch.cuda.synchronize()
     clear_ok = torch.tensor([1 if torch.equal(last, ref) else 0], dtype=torch.int64, device=dev)
-    del ref
     if world > 1:
         dist.all_reduce(clear_ok, op=dist.ReduceOp.MIN)
     clear_check = bool(int(clear_ok.item()))
-    if reducer is not None:
-        reducer.submit(last, chk_info0["dose_box_min"], chk_info0["dose_box_max"])
-        reducer.drain()
-
-    # N>1 self-check (untimed): the reduced volume on rank 0 must hold the sum of all ranks' fields
+    # (b) N>1: the slabs of all ranks together hold the sum of all fields (each rank also transfers its own field unclipped)
     reduce_check = None
     if world > 1:
-        d = doses[0]
-        reducer.release(d)
-        d.zero_()
-        fld.compute(d.data_ptr())
-        _, chk_info = fld.finish()
-        local_sum = d.sum(dtype=torch.float64).reshape(1)
-        reducer.submit(d, chk_info["dose_box_min"], chk_info["dose_box_max"])
-        reducer.drain()
-        dist.all_reduce(local_sum, op=dist.ReduceOp.SUM)
-        if rank == 0:
-            total = float(d.sum(dtype=torch.float64).item())
-            reduce_check = abs(total - float(local_sum.item())) / max(float(local_sum.item()), 1e-300)
+        slab_sum = last.sum(dtype=torch.float64).reshape(1)
+        ref.zero_()
+        f_chk.transfer(ref.data_ptr())
+        f_chk.finish()
+        torch.cuda.synchronize()
+        field_sum = ref.sum(dtype=torch.float64).reshape(1)
+        dist.all_reduce(slab_sum, op=dist.ReduceOp.SUM)
+        dist.all_reduce(field_sum, op=dist.ReduceOp.SUM)
+        reduce_check = abs(float(slab_sum.item()) - float(field_sum.item())) / max(float(field_sum.item()), 1e-300)
+    del ref
 
     if rank == 0:
         info["_steps"] = beam.tracerSteps
         stage_ms = {k: buckets[k] / args.steps for k in buckets if k.endswith("_ms")}
-        alg = algorithmic_bytes(info, scn.dims)
+        ct_fp = None
+        oracle = None
+        if not args.no_cpu and world == 1:
+            from oracle import oracle
+            ncpu = args.cpu_threads or min(16, os.cpu_count() or 1)
+            oracle.set_threads(ncpu)
+            ct_fp = oracle.ct_footprint(scn, beam)
+        alg = algorithmic_bytes(info, scn.dims, ct_fp)
         ks_ms = stage_ms["superp_kernel_ms"]
         ks_gbs = alg["superposition"] / (ks_ms * 1e-3) / 1e9 if ks_ms > 0 else 0.0
-        traffic = None
+        traffic, pmc = None, {}
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get("k_superpose", {}).get("hbm_bytes_per_launch")
+                pmc = json.load(open(tfile)).get("k_superpose", {})
+                traffic = pmc.get("hbm_bytes_per_launch")
             except Exception:
-                traffic = None
+                traffic, pmc = None, {}
+        mfma_per_launch = pmc.get("mfma_insts_per_launch")
+        valu_per_launch = pmc.get("valu_insts_per_launch")
+        roof = {"kernel": "rtd::k_superpose_mfma", "bound": "valu+mfma issue", "achieved": round(ks_gbs, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(ks_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "avg_launch_ms": round(ks_ms, 4), "algorithmic_bytes_per_launch": alg["superposition"],
+                "note": "contract form: algorithmic bytes = SURVEY.md 8(d) superposition term 8*(R+P)*sum(A_l), against the 8 TB/s HBM peak. "
+                        "The kernel is NOT HBM-bound: PMC counters (profiles/, per launch) show its SIMDs busy issuing vector ALU + f32-MFMA "
+                        "instructions (issue_cycle_frac); traffic = (2*FETCH_SIZE+WRITE_SIZE)*1024 from profiles/traffic.json"}
+        if mfma_per_launch and ks_ms > 0:
+            roof["mfma_tflops"] = round(mfma_per_launch * 2048 / (ks_ms * 1e-3) / 1e12, 2)      # 16x16x4 MFMA = 1024 MACs
+            roof["mfma_peak_tflops"] = F32_MATRIX_PEAK_TF
+            if valu_per_launch and pmc.get("simd_cycles_per_launch"):
+                roof["issue_cycle_frac"] = round((4.0 * valu_per_launch + 32.0 * mfma_per_launch) / pmc["simd_cycles_per_launch"], 3)
         result = {
             "metric": "Mvoxels/s dose deposited (%d^3 CT, 1 field per GPU)" % n,
             "value": round(world * n_vox / elapsed * args.steps / 1e6, 3),
@@ -265,55 +318,106 @@ def main():
                                    "10x10 spots x 20 layers = 2000 spots, 512 tracer steps, 1 mm rays" % (n, world),
                        "plans_in_flight_on_streams": n_streams, "ray_grid": info["ray_dims"], "live_steps": info["live_steps"], "max_radius": info["max_radius"],
                        "bbox_voxels": int(np.prod([info["bbox_max"][i] - info["bbox_min"][i] + 1 for i in range(3)])),
-                       "reduce": ("none" if world == 1 else
-                                  "point-to-point reduce-scatter + gather over xGMI (rccl send/recv): every rank sends the pieces of its dose box "
-                                  "(rtd_field_info.dose_box) to the ranks that own those slabs, owners add, then send their complete slab "
-                                  "to rank 0; overlapped with the next plan" if reduce_mode == "slab" else
-                                  "each rank sends its packed dose box (rtd_field_info.dose_box) to rank 0 (rccl send/recv over its own xGMI "
-                                  "link), rank 0 adds the N-1 boxes; overlapped with the next plan")},
+                       "ct_footprint_voxels": ct_fp,
+                       "exchange": ("none" if world == 1 else
+                                    "one RCCL all-gather of the packed BEV slabs per plan (%d x %.1f MB), overlapped with the next plan's kernels; every "
+                                    "rank transfers every field, in field order, into its slab of the dose volume (axis %d, ranges %s): the volume stays "
+                                    "sharded by slabs, no dose data crosses xGMI" % (world, ex.cap / 1e6, ex.axis, ex.ranges))},
             "ms_plan": round(ms_per_step, 4),
+            "ms_plan_latency": round(ms_latency, 4),
             "reduce_check_rel_err": reduce_check, "clear_check": clear_check,
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "algorithmic_bytes": alg,
             "path_gbs": round(alg["total"] / (stage_ms["total_ms"] * 1e-3) / 1e9, 2),
-            "roofline": {"kernel": "rtd::k_superpose_mfma", "bound": "hbm", "achieved": round(ks_gbs, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(ks_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "avg_launch_ms": round(ks_ms, 4), "algorithmic_bytes_per_launch": alg["superposition"],
-                         "note": "algorithmic bytes = SURVEY.md 8(d) superposition term 8*(R+P)*sum(A_l); the kernel is bound by vector + f32-matrix "
-                                 "issue cycles (91 % of its SIMD cycles, DESIGN.md section 4), not by HBM; traffic = (2*FETCH_SIZE+WRITE_SIZE)*1024 from profiles/traffic.json"},
+            "path_frac_of_hbm_peak": round(alg["total"] / (stage_ms["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "roofline": roof,
         }
-        if not args.no_cpu and world == 1:
-            from oracle import oracle
-            ncpu = args.cpu_threads or min(16, os.cpu_count() or 1)
-            oracle.set_threads(ncpu)
+        if oracle is not None:
+            # ---- CPU baseline: the oracle (kind "port") on this host. Headline sample: 4 fields of the bench workload on ncpu threads. ----
             cpu_dose = np.zeros_like(scn.ct)
             c0 = time.perf_counter()
             of = oracle.run_field(scn, beam, cpu_dose, keep_layers=False)
             cpu_first = time.perf_counter() - c0
-            # bounded sample of ~10-30 s of CPU work: the N=1 field plus the three other C4 gantry angles
             extra = scenarios.hetero_ct(es, n=n, angles=[90.0, 180.0, 270.0], ct=ct_np)
             scratch = np.zeros_like(scn.ct)
             for b2 in extra.beams:
                 oracle.run_field(extra, b2, scratch, keep_layers=False).close()
             cpu_s = time.perf_counter() - c0
             n_cpu_fields = 1 + len(extra.beams)
+            # one thread: the bench field (C3) once, and the mandatory C1 (water cube 128^3, one layer) on 1 and ncpu threads
+            oracle.set_threads(1)
+            scratch[:] = 0.0
+            c1 = time.perf_counter()
+            oracle.run_field(scn, beam, scratch, keep_layers=False).close()
+            cpu_1t = time.perf_counter() - c1
             del scratch
+            c1scn = scenarios.water_cube(es, n=128, n_layers=1)
+            c1d = np.zeros_like(c1scn.ct)
+            c1 = time.perf_counter()
+            oracle.run_field(c1scn, c1scn.beams[0], c1d, keep_layers=False).close()
+            c1_1t = time.perf_counter() - c1
+            oracle.set_threads(ncpu)
+            c1d[:] = 0.0
+            c1 = time.perf_counter()
+            oracle.run_field(c1scn, c1scn.beams[0], c1d, keep_layers=False).close()
+            c1_nt = time.perf_counter() - c1
+            host = dose.cpu().numpy() if world == 1 else None
+            result["cpu_baseline"] = {
+                "value": round(n_cpu_fields * n_vox / cpu_s / 1e6, 3), "unit": "Mvoxels/s", "cores": ncpu, "kind": "port",
+                "cpu_model": cpu_model(),
+                "sample": "%d fields of the same workload (the N=1 field + gantry 90/180/270), CPU oracle (oracle/rtd_oracle.c) "
+                          "with %d OpenMP threads: %.1f s wall = %.0f CPU-s; first field alone %.2f s"
+                          % (n_cpu_fields, ncpu, cpu_s, cpu_s * ncpu, cpu_first),
+                "one_thread": {"value": round(n_vox / cpu_1t / 1e6, 3), "unit": "Mvoxels/s", "seconds_per_field": round(cpu_1t, 3), "workload": "C3 field, 1 thread"},
+                "c1": {"workload": "C1: water cube 128^3, one G000 field, one energy layer (BASELINE.json configs[0])",
+                       "one_thread_s": round(c1_1t, 4), "all_threads_s": round(c1_nt, 4),
+                       "one_thread_mvox_s": round(c1scn.n_voxels / c1_1t / 1e6, 3), "all_threads_mvox_s": round(c1scn.n_voxels / c1_nt / 1e6, 3)}}
+            # the timed loop's last volume was cleared by the self-check: recompute the field for the parity leg
+            dose.zero_()
+            fld.compute(dose.data_ptr())
+            fld.finish()
+            torch.cuda.synchronize()
             host = dose.cpu().numpy()
             rate, n_eval, gmax = oracle.gamma_pass_rate(cpu_dose, host, scn.spacing)
             thr = cpu_dose > 0.1 * cpu_dose.max()
             max_rel = float((np.abs(host - cpu_dose)[thr] / cpu_dose[thr]).max())
-            result["cpu_baseline"] = {"value": round(n_cpu_fields * n_vox / cpu_s / 1e6, 3), "unit": "Mvoxels/s", "cores": ncpu, "kind": "port",
-                                      "sample": "%d fields of the same workload (the N=1 field + gantry 90/180/270), CPU oracle (oracle/rtd_oracle.c) "
-                                                "with %d OpenMP threads: %.1f s wall = %.0f CPU-s; first field alone %.2f s"
-                                                % (n_cpu_fields, ncpu, cpu_s, cpu_s * ncpu, cpu_first)}
             result["parity"] = {"gamma_1pct_1mm_pass": rate, "gamma_voxels": n_eval, "gamma_max": round(gmax, 4),
                                 "max_rel_diff_above_10pct": max_rel}
             of.close()
+            # ---- end to end, as the reference times it (kernel_wrapper.cu:410-414 -> 1356-1360): context exists; LUT + CT upload, dose up,
+            #      all kernels, dose down, from page-locked host buffers (HostPinnedImage3D, host_image_3d.cuh:23-32) ----
+            e2e = {}
+            ct_host = np.ascontiguousarray(ct_np)
+            dose_host = np.zeros_like(ct_host)
+            engine.host_register(ct_host)
+            engine.host_register(dose_host)
+            try:
+                with engine.Plan([dev_index]) as pl:
+                    for name in ("first_call", "second_call"):
+                        dose_host[:] = 0.0
+                        e0 = time.perf_counter()
+                        pl.set_luts(es)
+                        pl.set_ct(ct_host)
+                        _, pt = pl.compute([beam], dose_host)
+                        e2e[name] = {"ms": round(1000.0 * (time.perf_counter() - e0), 3),
+                                     "compute_call": {k: round(v, 3) for k, v in pt.items() if k.endswith("_ms")}}
+                    e2e["matches_resident_path"] = bool(np.array_equal(dose_host, host))
+            finally:
+                engine.host_unregister(ct_host)
+                engine.host_unregister(dose_host)
+            e2e["what"] = ("LUT + %d MB CT upload, %d MB dose up, all kernels of the field, %d MB dose down; pinned host buffers; first_call "
+                           "includes the workspace allocations (as the reference's per-beam cudaMallocs do), second_call reuses them"
+                           % (ct_host.nbytes // 10 ** 6, dose_host.nbytes // 10 ** 6, dose_host.nbytes // 10 ** 6))
+            result["ms_plan_end_to_end"] = e2e
         print(json.dumps(result))
     for f in flds:
         f.destroy()
+    if ex is not None:
+        for f in ex.remote.values():
+            f.destroy()
     eng.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -37,6 +37,8 @@ namespace {
 
 struct Config {
     unsigned short gpu_id = 0;
+    std::vector<int> gpu_ids;       // extension: several devices -> beams are computed on several GPUs (rtd_plan_*)
+    bool fine_grained_timing = false;   // the reference's FINE_GRAINED_TIMING build option, at run time
     std::string ct_dir, rtplan, output_directory, lut_dir, spot_list, dump_spot_list;
     std::vector<std::string> beams;
     bool water_cube = false;
@@ -78,6 +80,8 @@ void printHelp() {
                  "Usage: raytracedicom [OPTIONS]\n\nOptions:\n"
                  "  -h,--help                   Print this help message and exit\n"
                  "  --gpu_id UINT               ID of the GPU to use for simulation, starts from 0.\n"
+                 "  --gpu_ids UINT ...          Several GPUs: the beams of the plan are computed on all of them (same dose, bit for bit).\n"
+                 "  --fine_grained_timing       Per-field timing lines of the reference's FINE_GRAINED_TIMING build.\n"
                  "  --ct_dir TEXT               Patient CT directory. It must contain all the DICOM CT slices.\n"
                  "  --rtplan TEXT:FILE          Path of the RTPLAN DICOM file to read.\n"
                  "  --beams TEXT ...            All beam names to include in the calculation\n"
@@ -108,6 +112,11 @@ void assign(Config& c, const std::string& key, const std::vector<std::string>& v
         return vals[0];
     };
     if (key == "gpu_id") c.gpu_id = (unsigned short)parseUInt(key, one(), 65535);
+    else if (key == "gpu_ids") { if (vals.empty()) usageError("--gpu_ids: At least 1 required"); c.gpu_ids.clear(); for (const auto& v : vals) c.gpu_ids.push_back((int)parseUInt(key, v, 65535)); }
+    else if (key == "fine_grained_timing") {
+        if (vals.empty()) c.fine_grained_timing = true;
+        else { const std::string v = vals[0]; c.fine_grained_timing = (v == "true" || v == "1" || v == "on" || v == "yes"); }
+    }
     else if (key == "ct_dir") c.ct_dir = one();
     else if (key == "rtplan") c.rtplan = one();
     else if (key == "output_directory") c.output_directory = one();
@@ -177,7 +186,7 @@ int main(int argc, char** argv) {
         if (eq != std::string::npos) { vals.push_back(key.substr(eq + 1)); key = key.substr(0, eq); }
         while (i + 1 < argc && std::string(argv[i + 1]).rfind("--", 0) != 0) {
             vals.push_back(argv[++i]);
-            if (key != "beams") break;                                  // only --beams takes several values
+            if (key != "beams" && key != "gpu_ids") break;              // only --beams and --gpu_ids take several values
         }
         if (key == "config_file") {
             if (vals.size() != 1) usageError("--config_file: 1 required TEXT missing");
@@ -210,10 +219,14 @@ int main(int argc, char** argv) {
     if (!config.spot_list.empty() && !config.water_cube) usageError("--spot_list requires --water_cube (CT input is not built yet)");
     std::cout << configToStr(config) << std::endl;
 
+    const std::vector<int> gpus = config.gpu_ids.empty() ? std::vector<int>{(int)config.gpu_id} : config.gpu_ids;
+    rtd_options opt;
+    rtd_default_options(&opt);
+    opt.fine_grained_timing = config.fine_grained_timing ? 1 : 0;
     try {
         if (!config.water_cube) {                                       // DICOM input (SURVEY section 8 rows f2 + f3)
-            runDicomPlan(config.lut_dir, config.output_directory, config.ct_dir, config.rtplan, config.beams, (int)config.gpu_id,
-                         config.start_depth, (int)config.tracer_steps);
+            runDicomPlan(config.lut_dir, config.output_directory, config.ct_dir, config.rtplan, config.beams, gpus,
+                         config.start_depth, (int)config.tracer_steps, nullptr, &opt);
             return 0;
         }
         if (!config.dump_spot_list.empty()) {
@@ -223,9 +236,9 @@ int main(int argc, char** argv) {
             return 0;
         }
         if (!config.spot_list.empty())
-            runSpotListOnWaterCube(config.lut_dir, config.output_directory, config.water_cube_edge, config.spot_list, (int)config.gpu_id);
+            runSpotListOnWaterCube(config.lut_dir, config.output_directory, config.water_cube_edge, config.spot_list, gpus, &opt);
         else
-        runWaterCube(config.lut_dir, config.output_directory, config.water_cube_edge, config.layers, (int)config.gpu_id);
+        runWaterCube(config.lut_dir, config.output_directory, config.water_cube_edge, config.layers, gpus, &opt);
     } catch (const std::exception& e) {
         std::cerr << "error: " << e.what() << std::endl;
         return 1;

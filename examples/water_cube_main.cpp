@@ -12,7 +12,7 @@ int main(int argc, char** argv) {
     const unsigned int nLayers = argc > 4 ? std::atoi(argv[4]) : 20;
     const int gpuId = argc > 5 ? std::atoi(argv[5]) : 0;
     try {
-        runWaterCube(lutDir, outDir, n, nLayers, gpuId);
+        runWaterCube(lutDir, outDir, n, nLayers, std::vector<int>{gpuId});
     } catch (const std::exception& e) {
         std::cerr << "error: " << e.what() << std::endl;
         return 1;

@@ -131,7 +131,8 @@ inline void readSpotList(const std::string& path, std::vector<rtd_plan::Spot>& s
 // main.cu:100-216): CT -> HU+1000 + imIdxToWorld (dicom_reader.cpp), beams -> BeamSettings (rtd_plan.hpp), dose grid = CT grid.
 // startDepth / tracerSteps <= 0 mean "cover the CT along the beam axis".
 inline void runDicomPlan(const std::string& lutDir, const std::string& outDir, const std::string& ctDir, const std::string& planFile,
-                         const std::vector<std::string>& beamNamesIn, int gpuId, float startDepth, int tracerSteps, std::vector<float>* doseOut = nullptr) {
+                         const std::vector<std::string>& beamNamesIn, const std::vector<int>& gpuIds, float startDepth, int tracerSteps, std::vector<float>* doseOut = nullptr,
+                         const rtd_options* opt = nullptr) {
     clock_t t = clock();
     EnergyStruct ciddData = energyReader(lutDir, /*waterCubeTest=*/false);
     std::cout << "Read energy matrix: " << static_cast<float>(clock() - t) / CLOCKS_PER_SEC << " seconds.\n\n";
@@ -168,7 +169,7 @@ inline void runDicomPlan(const std::string& lutDir, const std::string& outDir, c
         beams.push_back(f.beamSettings(weightImages.back().get()));
     }
     std::cout << "Executing code on GPU...\n\n";
-    cudaWrapperProtons(&imVol, &doseVol, beams, ciddData, std::cout, gpuId);
+    cudaWrapperProtons(&imVol, &doseVol, beams, ciddData, std::cout, gpuIds, opt);
     std::cout << "Done!\n\n";
     std::ofstream fout((outDir + "/dose.dat").c_str(), std::ios::out | std::ios::binary);                                       // main.cu:211-216
     fout.write(reinterpret_cast<const char*>(dose.data()), dose.size() * sizeof(float));
@@ -179,7 +180,7 @@ inline void runDicomPlan(const std::string& lutDir, const std::string& outDir, c
 }
 
 // Dose of a plan given as a spot list on the water cube (CT input proper is SURVEY section 8 row f3).
-inline void runSpotListOnWaterCube(const std::string& lutDir, const std::string& outDir, unsigned int n, const std::string& spotFile, int gpuId) {
+inline void runSpotListOnWaterCube(const std::string& lutDir, const std::string& outDir, unsigned int n, const std::string& spotFile, const std::vector<int>& gpuIds, const rtd_options* opt = nullptr) {
     EnergyStruct ciddData = energyReader(lutDir, /*waterCubeTest=*/true);
     WaterCube w(n);
     std::vector<rtd_plan::Spot> spots;
@@ -194,12 +195,12 @@ inline void runSpotListOnWaterCube(const std::string& lutDir, const std::string&
     std::vector<BeamSettings> beams;
     beams.push_back(f.beamSettings(&spotWeights));
     std::cout << "Executing code on GPU...\n\n";
-    cudaWrapperProtons(&imVol, &doseVol, beams, ciddData, std::cout, gpuId);
+    cudaWrapperProtons(&imVol, &doseVol, beams, ciddData, std::cout, gpuIds, opt);
     std::cout << "Done!\n\n";
     writeDoseAndReport(w, outDir);
 }
 
-inline void runWaterCube(const std::string& lutDir, const std::string& outDir, unsigned int n, unsigned int nLayers, int gpuId) {
+inline void runWaterCube(const std::string& lutDir, const std::string& outDir, unsigned int n, unsigned int nLayers, const std::vector<int>& gpuIds, const rtd_options* opt = nullptr) {
     EnergyStruct ciddData = energyReader(lutDir, /*waterCubeTest=*/true);
     const uint3 dim = make_uint3(n, n, n);
     const size_t N = (size_t)n * n * n;
@@ -235,7 +236,7 @@ inline void runWaterCube(const std::string& lutDir, const std::string& outDir, u
     beams.push_back(BeamSettings(&spotWeights, energiesPerU, sigmas, make_float2(1.0f, 1.0f), 512, sourceDist, fanIdxToFan,
                                  gantryToImIdx, gantryToImIdx));                                                             // main.cu:192-197
     std::cout << "Executing code on GPU...\n\n";
-    cudaWrapperProtons(&imVol, &doseVol, beams, ciddData, std::cout, gpuId);
+    cudaWrapperProtons(&imVol, &doseVol, beams, ciddData, std::cout, gpuIds, opt);
     std::cout << "Done!\n\n";
     std::ofstream fout((outDir + "/dose.dat").c_str(), std::ios::out | std::ios::binary);
     fout.write(reinterpret_cast<const char*>(doseData.data()), doseData.size() * sizeof(float));

@@ -117,6 +117,10 @@ typedef struct rtd_timing {
     float total_ms;               /* first kernel to last kernel of the field    */
     int32_t superp_launches;      /* number of superposition kernel launches     */
     float superp_kernel_ms;       /* the dominant kernel alone (k_superpose_mfma), inside superp_ms */
+    uint32_t ray_dims[2];         /* what the reference's timing lines quote: "trace WxH rays S steps", "N time(s)" per   */
+    uint32_t steps;               /* layer, "transform N voxels" (kernel_wrapper.cu:1298-1307)                           */
+    uint32_t n_layers;
+    int64_t transfer_voxels;      /* voxels of the dose box the transfer visited */
     int32_t reserved[2];
 } rtd_timing;
 

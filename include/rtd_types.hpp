@@ -1,8 +1,8 @@
 // rtd_types.hpp — stand-alone mirrors of the reference's host value types, for C++ callers that do not have the
 // reference tree (or CUDA's float2/float3/uint3) at hand. Same class names, constructors and accessors:
 //   Matrix3x3 (src/matrix_3x3.cuh), Float3AffineTransform (src/float3_affine_transform.cuh),
-//   Float3IdxTransform (src/float3_idx_transform.cuh), HostPinnedImage3D<T> (src/host_image_3d.cuh, non-owning,
-//   no page-locking here: the engine stages through its own transfers), BeamSettings (src/beam_settings.h),
+//   Float3IdxTransform (src/float3_idx_transform.cuh), HostPinnedImage3D<T> (src/host_image_3d.cuh: non-owning, the
+//   buffer is page-locked for the lifetime of the object like the reference's cudaHostRegister), BeamSettings (src/beam_settings.h),
 //   EnergyStruct (src/energy_struct.h), energyReader (src/energy_reader.h; text layout of SURVEY Appendix A).
 #pragma once
 
@@ -11,6 +11,8 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+
+#include "rtd.h"
 
 namespace rtd_types {
 
@@ -83,12 +85,20 @@ private:
 template <typename T>
 class HostPinnedImage3D {
 public:
-    HostPinnedImage3D(T* imagePtr, uint3 dimensions) : imPtr(imagePtr), dims(dimensions) {}
+    // page-locks the caller's buffer (host_image_3d.cuh:23-32); without a GPU the registration fails and the image is pageable
+    HostPinnedImage3D(T* imagePtr, uint3 dimensions) : imPtr(imagePtr), dims(dimensions) {
+        pinned = imagePtr && rtd_host_register((void*)imPtr, (size_t)dims.x * dims.y * dims.z * sizeof(T)) == RTD_OK;
+    }
+    ~HostPinnedImage3D() { if (pinned) rtd_host_unregister((void*)imPtr); }   // host_image_3d.cuh:45-48
+    HostPinnedImage3D(const HostPinnedImage3D&) = delete;
+    HostPinnedImage3D& operator=(const HostPinnedImage3D&) = delete;
     T* getImData() const { return imPtr; }
     uint3 getDims() const { return dims; }
+    bool isPinned() const { return pinned; }
 private:
     T* const imPtr;     // not owned
     const uint3 dims;
+    bool pinned = false;
 };
 
 class BeamSettings {   // src/beam_settings.h:31,101-109
@@ -96,26 +106,26 @@ public:
     BeamSettings(HostPinnedImage3D<float>* spotWeights, const std::vector<float>& beamEnergies, const std::vector<float2>& spotSigmas,
                  float2 raySpacing, unsigned int tracerSteps, float2 sourceDist, Float3IdxTransform spotIdxToGantry,
                  const Float3AffineTransform& gantryToImIdx, const Float3AffineTransform& gantryToDoseIdx)
-        : sWghts(spotWeights), bEnergies(beamEnergies), sSigmas(spotSigmas), rSpacing(raySpacing), steps(tracerSteps), sDist(sourceDist),
-          sITG(spotIdxToGantry), gTII(gantryToImIdx), gTDI(gantryToDoseIdx) {}
-    HostPinnedImage3D<float>* getWeights() { return sWghts; }
-    std::vector<float>& getEnergies() { return bEnergies; }
-    std::vector<float2>& getSpotSigmas() { return sSigmas; }
-    float2 getRaySpacing() const { return rSpacing; }
-    unsigned int getSteps() const { return steps; }
-    float2 getSourceDist() const { return sDist; }
-    Float3IdxTransform getSpotIdxToGantry() const { return sITG; }
-    Float3AffineTransform getGantryToImIdx() const { return gTII; }
-    Float3AffineTransform getGantryToDoseIdx() const { return gTDI; }
+        : weightMaps_(spotWeights), layerEnergies_(beamEnergies), layerSigmas_(spotSigmas), rayPitch_(raySpacing), nSteps_(tracerSteps),
+          sad_(sourceDist), spotGrid_(spotIdxToGantry), toImage_(gantryToImIdx), toDose_(gantryToDoseIdx) {}
+    HostPinnedImage3D<float>* getWeights() { return weightMaps_; }
+    std::vector<float>& getEnergies() { return layerEnergies_; }
+    std::vector<float2>& getSpotSigmas() { return layerSigmas_; }
+    float2 getRaySpacing() const { return rayPitch_; }
+    unsigned int getSteps() const { return nSteps_; }
+    float2 getSourceDist() const { return sad_; }
+    Float3IdxTransform getSpotIdxToGantry() const { return spotGrid_; }
+    Float3AffineTransform getGantryToImIdx() const { return toImage_; }
+    Float3AffineTransform getGantryToDoseIdx() const { return toDose_; }
 private:
-    HostPinnedImage3D<float>* sWghts;
-    std::vector<float> bEnergies;
-    std::vector<float2> sSigmas;
-    float2 rSpacing;
-    unsigned int steps;
-    float2 sDist;
-    Float3IdxTransform sITG;
-    Float3AffineTransform gTII, gTDI;
+    HostPinnedImage3D<float>* weightMaps_;      // [layer][ny][nx] particle numbers, not owned
+    std::vector<float> layerEnergies_;          // MeV/u per layer
+    std::vector<float2> layerSigmas_;           // spot sigma (x, y) per layer, mm at iso in air
+    float2 rayPitch_;                           // mm between rays at iso
+    unsigned int nSteps_;
+    float2 sad_;                                // apparent source distances, mm (may be +inf)
+    Float3IdxTransform spotGrid_;
+    Float3AffineTransform toImage_, toDose_;
 };
 
 struct EnergyStruct {   // src/energy_struct.h:13-31

@@ -123,6 +123,17 @@ def set_weight_bits(bits):
     lib().orc_set_weight_bits(int(bits))
 
 
+def ct_footprint(scn, beam):
+    """Number of distinct CT voxels the tracer of this field reads (N_fp of the algorithmic-byte model)."""
+    L = lib()
+    L.orc_footprint_start.argtypes = [C.c_size_t]
+    L.orc_footprint_stop.restype = C.c_longlong
+    L.orc_footprint_start(int(scn.ct.size))
+    scratch = np.zeros_like(scn.ct)
+    run_field(scn, beam, scratch, keep_layers=False).close()
+    return int(L.orc_footprint_stop())
+
+
 def set_threads(n):
     lib().orc_set_threads(int(n))
 

@@ -434,6 +434,26 @@ void orc_erf_diffs(float rSigmaEff, int rad, float* out) {
 /* ------------------------------------------------------------------------------------------ */
 /* Stage 1: fillBevDensityAndSp (kernel_wrapper.cu:130-187).                                   */
 
+/* CT footprint of the tracer = number of DISTINCT CT voxels its trilinear samples read (the N_fp of the algorithmic-byte
+ * model). While a map is armed (orc_footprint_start) every sample marks its in-range corner voxels. */
+static unsigned char* g_touch = NULL;
+static size_t g_touch_n = 0;
+void orc_footprint_start(size_t nVoxels) { free(g_touch); g_touch = (unsigned char*)calloc(nVoxels ? nVoxels : 1, 1); g_touch_n = g_touch ? nVoxels : 0; }
+long long orc_footprint_stop(void) {
+    long long c = 0;
+    for (size_t i = 0; i < g_touch_n; ++i) c += g_touch[i];
+    free(g_touch); g_touch = NULL; g_touch_n = 0;
+    return c;
+}
+static inline void touch_ct(int nx, int ny, int nz, float px, float py, float pz) {
+    if (!(px > -1.0f && py > -1.0f && pz > -1.0f && px < (float)nx && py < (float)ny && pz < (float)nz)) return;
+    const int x0 = (int)floorf(px), y0 = (int)floorf(py), z0 = (int)floorf(pz);
+    for (int dz = 0; dz < 2; ++dz) for (int dy = 0; dy < 2; ++dy) for (int dx = 0; dx < 2; ++dx) {
+        const int x = x0 + dx, y = y0 + dy, z = z0 + dz;
+        if (x >= 0 && y >= 0 && z >= 0 && x < nx && y < ny && z < nz) g_touch[((size_t)z * ny + y) * nx + x] = 1;   /* (benign race: all writers store 1) */
+    }
+}
+
 static void stage_trace(const float* ct, const int ctd[3], const rtd_luts* l, const tracer_params* tp,
                         int W, int H, float* bevDensity, float* bevCumulSp, int* firstInside, int* firstOutside) {
     const size_t memStep = (size_t)W * H;
@@ -448,6 +468,7 @@ static void stage_trace(const float* ct, const int ctd[3], const rtd_luts* l, co
             int beforeFirstInside = -1, lastInside = -1;
             for (unsigned int i = 0; i < tp->steps; ++i) {
                 float huPlus1000 = sample3d_border(ct, ctd[0], ctd[1], ctd[2], pos.x, pos.y, pos.z);
+                if (g_touch && g_touch_n == (size_t)ctd[0] * ctd[1] * ctd[2]) touch_ct(ctd[0], ctd[1], ctd[2], pos.x, pos.y, pos.z);
                 cumulHuPlus1000 += huPlus1000;
                 bevDensity[idx] = sample1d_clamp(l->density_vector, l->n_density_samples, huPlus1000 * tp->densityScale);
                 cumulSp += stepLen * sample1d_clamp(l->sp_vector, l->n_sp_samples, huPlus1000 * tp->spScale);

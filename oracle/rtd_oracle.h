@@ -15,6 +15,10 @@ typedef struct orc_field_s* orc_field;
 void orc_set_threads(int n);
 void orc_set_weight_bits(int bits);
 int orc_get_max_threads(void);
+/* distinct CT voxels read by the tracer of the fields run between start and stop (N_fp of SURVEY.md 8(d)) */
+void orc_footprint_start(size_t nVoxels);
+long long orc_footprint_stop(void);
+float orc_pow_det(float x, float y);
 
 /* host helpers (vector_find.h, vector_interpolate.h) */
 float orc_find_max(const float* list, int n);

@@ -18,5 +18,6 @@ cd $R
 cp $OUT/stats/s_kernel_stats.csv $OUT/kernel_stats.csv
 python3 profiles/pmc_summary.py $OUT/fetch/p_counter_collection.csv $OUT/write/p_counter_collection.csv > $OUT/pmc_fetch_write_kb.txt
 python3 profiles/pmc_summary.py k_superpose_mfma $OUT/sq1/p_counter_collection.csv $OUT/sq2/p_counter_collection.csv > $OUT/pmc_sq_superpose.txt
-python3 profiles/pmc_summary.py --traffic-json $OUT/fetch/p_counter_collection.csv $OUT/write/p_counter_collection.csv > $OUT/traffic.json
+python3 profiles/pmc_summary.py k_fill $OUT/sq1/p_counter_collection.csv $OUT/sq2/p_counter_collection.csv > $OUT/pmc_sq_fill.txt
+python3 profiles/pmc_summary.py --traffic-json $OUT/fetch/p_counter_collection.csv $OUT/write/p_counter_collection.csv $OUT/sq1/p_counter_collection.csv $OUT/sq2/p_counter_collection.csv > $OUT/traffic.json
 tail -1 $OUT/stats.log | cut -c1-400

@@ -34,6 +34,15 @@ def traffic(paths):
         out[m.group(1)] = {"fetch_size_kib": round(f, 3), "write_size_kib": round(w, 3), "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
     if "k_superpose_mfma" in out:
         out["k_superpose"] = dict(out["k_superpose_mfma"], kernel="rtd::k_superpose_mfma")
+        # issue counters of the dominant kernel, when the SQ passes are given too (bench.py: roofline.issue_cycle_frac, mfma_tflops)
+        for k, d in collect(paths).items():
+            if "k_superpose_mfma" not in k: continue
+            mean = lambda c: sum(d[c]) / len(d[c]) if c in d else None
+            if mean("SQ_INSTS_MFMA"): out["k_superpose"]["mfma_insts_per_launch"] = int(mean("SQ_INSTS_MFMA"))
+            if mean("SQ_INSTS_VALU"): out["k_superpose"]["valu_insts_per_launch"] = int(mean("SQ_INSTS_VALU"))
+            if mean("SQ_INSTS_SALU"): out["k_superpose"]["salu_insts_per_launch"] = int(mean("SQ_INSTS_SALU"))
+            # GRBM_GUI_ACTIVE sums the 8 XCDs: cycles of the launch = /8; SIMD-cycles = x 256 CUs x 4 SIMDs
+            if mean("GRBM_GUI_ACTIVE"): out["k_superpose"]["simd_cycles_per_launch"] = int(mean("GRBM_GUI_ACTIVE") / 8 * 1024)
     print(json.dumps(out, indent=1))
 
 if __name__ == "__main__":

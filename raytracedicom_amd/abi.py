@@ -68,11 +68,15 @@ class RtdTiming(C.Structure):
     _fields_ = [
         ("raytracing_ms", C.c_float), ("prepare_energy_loop_ms", C.c_float), ("fill_idd_sigma_ms", C.c_float),
         ("prepare_superp_ms", C.c_float), ("superp_ms", C.c_float), ("transforming_ms", C.c_float),
-        ("total_ms", C.c_float), ("superp_launches", C.c_int32), ("superp_kernel_ms", C.c_float), ("reserved", C.c_int32 * 2),
+        ("total_ms", C.c_float), ("superp_launches", C.c_int32), ("superp_kernel_ms", C.c_float),
+        ("ray_dims", C.c_uint32 * 2), ("steps", C.c_uint32), ("n_layers", C.c_uint32), ("transfer_voxels", C.c_int64),
+        ("reserved", C.c_int32 * 2),
     ]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        d["ray_dims"] = list(d["ray_dims"])
+        return d
 
 
 class RtdFieldInfo(C.Structure):

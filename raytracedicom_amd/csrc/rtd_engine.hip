@@ -805,6 +805,10 @@ int rtd_field_finish(rtd_handle hh, rtd_field ff, rtd_timing* timing, rtd_field_
             if (f->transferred) RTD_HIP(h, hipEventElapsedTime(&timing->transforming_ms, f->ev[5], f->ev[6]));
         }
         timing->superp_launches = 2;   // k_superpose_mfma + k_superpose_reduce (the reference: up to 33 per layer)
+        timing->ray_dims[0] = (uint32_t)f->fc.W; timing->ray_dims[1] = (uint32_t)f->fc.H;
+        timing->steps = (uint32_t)f->fc.S; timing->n_layers = (uint32_t)f->fc.L;
+        timing->transfer_voxels = 1;
+        for (int i = 0; i < 3; ++i) timing->transfer_voxels *= (int64_t)std::max(st.tboxMax[i] - st.tboxMin[i] + 1, 0);
     }
     if (info) fillInfo(f, st, info);
     if (st.errorFlags & kErrRadiusOverflow)

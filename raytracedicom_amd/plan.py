@@ -461,3 +461,127 @@ class PipelinedSlabReduce(PipelinedBoxReduce):
                 self.done[id(dose_tensor)] = added                    # phase 1 is complete; phase 2 is finished by release() / drain()
                 pending = [(w, views, b, unpack) for w, views, b in items2] if items2 else [(None, None, None, None)]
         self.pending[id(dose_tensor)] = pending
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Exchange in beam's-eye view. What a field hands to the dose grid is its BEV dose cube (the cube the reference copies into a
+# 3-D texture before primTransfDiv samples it, kernel_wrapper.cu:1107-1141): on the 512^3 / 0.5 mm bench grid its non-zero
+# block is ~10 MB where the dose box it turns into is 60-83 MB. So the ranks all-gather the packed BEV blocks (ONE RCCL
+# collective per plan, N x ~10 MB, every xGMI link busy) and every rank runs the transfer of EVERY field — in field order,
+# i.e. the `+=` order of the sequential beam loop (kernel_wrapper.cu:601, :92) — restricted to ITS slab of the dose volume.
+# The plan's dose volume is left sharded by slabs across the GPUs (each rank copies its slab to the host over its own PCIe
+# link); no dose data crosses between GPUs, and the result is bit-identical to the one-GPU loop.
+
+def balanced_slabs(boxes, dims, world):
+    """Slabs for BevExchange: the dose grid is cut into `world` slabs along one axis so that the transfer work — for every slab
+    the voxels of ALL fields' dose boxes inside it — is as even as it can be. boxes: 6-int inclusive boxes (x0, y0, z0, x1, y1, z1),
+    an empty box has max < min. Returns (axis, [(lo, hi) inclusive index range per rank along that axis]); slabs tile [0, dims[axis])."""
+    valid = [b for b in boxes if all(b[3 + a] >= b[a] for a in range(3))]
+    best = None
+    for axis in (2, 1, 0):                                            # ties: z first (contiguous slabs of the [z][y][x] volume)
+        n = int(dims[axis])
+        prof = [0] * (n + 1)
+        for b in valid:
+            area = 1
+            for a in range(3):
+                if a != axis:
+                    area *= b[3 + a] - b[a] + 1
+            prof[max(b[axis], 0)] += area
+            prof[min(b[3 + axis], n - 1) + 1] -= area
+        load, run = [], 0
+        for i in range(n):
+            run += prof[i]
+            load.append(run)
+        total = sum(load)
+        cuts, acc, r = [0], 0, 1
+        for i in range(n):
+            acc += load[i]
+            while r < world and acc * world >= total * r and len(cuts) < world:
+                cuts.append(i + 1)
+                r += 1
+        while len(cuts) < world:
+            cuts.append(n)
+        cuts.append(n)
+        ranges = [(cuts[k], cuts[k + 1] - 1) for k in range(world)]
+        worst = max((sum(load[a:b + 1]) for a, b in ranges if b >= a), default=0)
+        if best is None or worst < best[0]:
+            best = (worst, axis, ranges)
+    return best[1], best[2]
+
+
+class BevExchange:
+    """All-gather of the packed BEV slabs + slab-clipped transfers of every field on every rank (see the comment above).
+
+    fields[r] for r != rank are geometry-only ("remote") field objects of the other ranks' beams; fields[rank] alternates between
+    the caller's own field objects. The objects need the methods of raytracedicom_amd.engine.Field used here (wait_plan,
+    export_bev, attach_bev, transfer, clear_dose_box) — the CPU tests drive this class with numpy stand-ins over gloo.
+    All device work is issued on the CURRENT torch stream, which must be the stream the engine launches on."""
+
+    def __init__(self, dist, rank, world, remote_fields, dims, new_bytes, data_ptr=lambda t: t.data_ptr(), n_buffers=2):
+        self.dist, self.rank, self.world, self.dims = dist, rank, world, tuple(int(d) for d in dims)
+        self.remote = remote_fields            # dict rank -> remote field object
+        self.new_bytes, self.data_ptr = new_bytes, data_ptr
+        self.n_buffers = n_buffers
+        self.cap = None
+        self.send, self.recv, self.work = [], [], []
+        self.boxes = None
+        self.axis, self.ranges = None, None
+
+    def setup(self, own_field):
+        """After the first compute_bev of the own field: message capacity (max over ranks), dose boxes, slab partition."""
+        import torch
+        info, nbytes = own_field.wait_plan()
+        dev = self.new_bytes(1).device
+        mine = torch.tensor([int(nbytes)] + [int(v) for v in info["dose_box_min"]] + [int(v) for v in info["dose_box_max"]], dtype=torch.int64, device=dev)
+        allv = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(allv, mine)
+        rows = torch.stack(allv).cpu().tolist()
+        self.cap = (max(int(r[0]) for r in rows) + 255) // 256 * 256
+        self.boxes = [[int(v) for v in r[1:7]] for r in rows]
+        self.axis, self.ranges = balanced_slabs(self.boxes, self.dims, self.world)
+        self.send = [self.new_bytes(self.cap) for _ in range(self.n_buffers)]
+        self.recv = [self.new_bytes(self.cap * self.world) for _ in range(self.n_buffers)]
+        self.work = [None] * self.n_buffers
+        return self
+
+    def clip(self):
+        """(lo, hi) inclusive dose-index box of this rank's slab."""
+        lo, hi = [0, 0, 0], [d - 1 for d in self.dims]
+        lo[self.axis], hi[self.axis] = self.ranges[self.rank]
+        return lo, hi
+
+    def post(self, own_field, b):
+        """Pack the own field's BEV slab into send buffer b and start the all-gather (left in flight)."""
+        own_field.export_bev(self.data_ptr(self.send[b]), self.cap)
+        self.work[b] = self.dist.all_gather_into_tensor(self.recv[b], self.send[b], async_op=True)
+
+    def complete(self, own_field, b, dose_ptr):
+        """Wait (in stream order) for all-gather b, then transfer every field, in field order, into this rank's slab of the volume."""
+        if self.work[b] is not None:
+            self.work[b].wait()
+            self.work[b] = None
+        lo, hi = self.clip()
+        if hi[self.axis] < lo[self.axis]:
+            return
+        base = self.data_ptr(self.recv[b])
+        for r in range(self.world):
+            if r == self.rank:
+                own_field.transfer(dose_ptr, lo, hi)
+            else:
+                f = self.remote[r]
+                f.attach_bev(base + r * self.cap)
+                f.transfer(dose_ptr, lo, hi)
+
+    def clear(self, own_field, b, dose_ptr):
+        """Zero what complete(own_field, b, dose_ptr) wrote (the fields' dose boxes inside this rank's slab)."""
+        lo, hi = self.clip()
+        if hi[self.axis] < lo[self.axis]:
+            return
+        base = self.data_ptr(self.recv[b])
+        for r in range(self.world):
+            if r == self.rank:
+                own_field.clear_dose_box(dose_ptr, lo, hi)
+            else:
+                f = self.remote[r]
+                f.attach_bev(base + r * self.cap)
+                f.clear_dose_box(dose_ptr, lo, hi)

@@ -113,7 +113,7 @@ def test_oblique_series_rescale_and_errors(tmp_path):
 
 
 @pytest.mark.gpu
-def test_cli_dicom_input_reproduces_the_water_cube_plan(synth, tmp_path):
+def test_cli_dicom_input_reproduces_the_water_cube_plan(orc, synth, tmp_path):
     """End to end: a DICOM CT (water, oblique-free but with the slice normal along -y of the patient so that a gantry-0 beam of a
     head-first supine patient runs along the image's -k axis) + an RT Ion Plan holding the reference's water-cube field give,
     through rtd_dicom.hpp + rtd_plan.hpp + the C++ shim, the dose of the built-in WATER_CUBE_TEST plan; two beams add up."""
@@ -150,15 +150,23 @@ def test_cli_dicom_input_reproduces_the_water_cube_plan(synth, tmp_path):
     beam = dict(name="G000", gantry=0.0, iso=(0.0, 0.0, 0.0), vsad=(np.inf, np.inf), layers=lay)
     dfx.write_ion_plan(plan, [beam, dict(beam, name="AGAIN")])
     common = base + ["--ct_dir", ct_dir, "--rtplan", plan, "--start_depth", "128", "--tracer_steps", "512"]
-    r = subprocess.run(common + ["--beams", "G000", "--output_directory", str(outs["dicom"])], capture_output=True, text=True, timeout=300)
+    env = dict(os.environ, RTD_DUMP_CALL=str(tmp_path / "dicom.call"))
+    r = subprocess.run(common + ["--beams", "G000", "--output_directory", str(outs["dicom"])], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr
+    # f3 against the oracle, not against the built-in plan only: the CT and the beam the DICOM reader produced, as they crossed the C ABI
+    from test_plan_import import _against_oracle
+    scn = _against_oracle(orc, synth, str(tmp_path / "dicom.call"), str(outs["dicom"] / "dose.dat"), voxel, water=False)
+    assert scn.ct.shape == (n, n, n) and float(scn.ct.min()) == 1000.0 == float(scn.ct.max())      # HU 0 -> HU+1000
     assert "%d spots in %d layer(s) on a 33x33 spot grid" % (33 * 33 * layers, layers) in r.stdout
     a = np.fromfile(str(outs["builtin"] / "dose.dat"), dtype=np.float32)
     b = np.fromfile(str(outs["dicom"] / "dose.dat"), dtype=np.float32)
     assert a.max() > 0
     np.testing.assert_allclose(b, a, rtol=2e-5, atol=1e-7 * float(a.max()))
-    r = subprocess.run(common + ["--beams", "G000", "AGAIN", "--output_directory", str(outs["two"])], capture_output=True, text=True, timeout=300)
+    env2 = dict(os.environ, RTD_DUMP_CALL=str(tmp_path / "two.call"))
+    r = subprocess.run(common + ["--beams", "G000", "AGAIN", "--output_directory", str(outs["two"]), "--gpu_ids", "0", "0"], capture_output=True,
+                       text=True, timeout=300, env=env2)
     assert r.returncode == 0, r.stderr
+    _against_oracle(orc, synth, str(tmp_path / "two.call"), str(outs["two"] / "dose.dat"), voxel, water=False)   # two beams on two handles (threads)
     c = np.fromfile(str(outs["two"] / "dose.dat"), dtype=np.float32)
     np.testing.assert_allclose(c, 2.0 * b, rtol=1e-6, atol=1e-7 * float(a.max()))
     # without overrides the tracer range is fitted to the CT: still the same physics (rays start outside the cube instead of inside it)

@@ -26,8 +26,25 @@ def test_spot_list_to_beam_settings(tmp_path):
     assert r.returncode == 0 and "rtd_plan ok" in r.stdout, r.stderr
 
 
+def _against_oracle(orc, synth, dump, dose_file, voxel, water=True):
+    """The CLI's dose.dat against the oracle run on exactly what the CLI passed through the C ABI (RTD_DUMP_CALL)."""
+    import call_dump
+    from raytracedicom_amd import luts
+    scn = call_dump.read(dump, luts.read_lut_dir(os.path.dirname(dump) + "/luts", water_cube_test=water), spacing=(voxel,) * 3)
+    ref = orc.compute(scn)
+    dose = np.fromfile(dose_file, dtype=np.float32).reshape(ref.shape)
+    mx = float(ref.max())
+    assert mx > 0
+    thr = ref > 1e-3 * mx
+    assert (np.abs(dose - ref)[thr] <= 1e-4 * ref[thr] + 1e-6 * mx).all(), float((np.abs(dose - ref)[thr] / ref[thr]).max())
+    assert np.abs(dose - ref).max() <= 1e-5 * mx
+    rate, n_eval, _ = orc.gamma_pass_rate(ref, dose, scn.spacing)
+    assert rate == 1.0 and n_eval > 0
+    return scn
+
+
 @pytest.mark.gpu
-def test_cli_spot_list_reproduces_the_builtin_plan(synth, tmp_path):
+def test_cli_spot_list_reproduces_the_builtin_plan(orc, synth, tmp_path):
     from raytracedicom_amd import luts
     d = str(tmp_path / "luts")
     luts.write_lut_dir(d, synth)
@@ -39,14 +56,26 @@ def test_cli_spot_list_reproduces_the_builtin_plan(synth, tmp_path):
         o.mkdir()
         outs.append(o)
     base = [cli, "--water_cube", "--water_cube_edge", "64", "--layers", "3", "--lut_dir", d]
-    r = subprocess.run(base + ["--output_directory", str(outs[0])], capture_output=True, text=True, timeout=300)
+    env = dict(os.environ, RTD_DUMP_CALL=str(tmp_path / "builtin.call"))
+    r = subprocess.run(base + ["--output_directory", str(outs[0]), "--fine_grained_timing"], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr
+    # the reference's FINE_GRAINED_TIMING text (kernel_wrapper.cu:598,604,1298-1307,1325,1349-1352)
+    for line in ("Copy data to GPU and bind to textures:", "Calculating field no. 0", "Time to trace 128x128 rays 512 steps:",
+                 "Time depositing IDD and calculating sigma 3 time(s):", "Time executing superposition 3 time(s):", "Kernel time to transform",
+                 "Time to copy dose back to host:", "Approximate total execution time (excluding GPU initialisation):"):
+        assert line in r.stdout, line
+    # f1 against the oracle, not against itself: the water-cube CLI run
+    _against_oracle(orc, synth, str(tmp_path / "builtin.call"), str(outs[0] / "dose.dat"), 256.0 / 64)
     spots = str(tmp_path / "spots.txt")
     r = subprocess.run(base + ["--output_directory", str(outs[1]), "--dump_spot_list", spots], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and os.path.exists(spots), r.stderr
-    r = subprocess.run(base + ["--output_directory", str(outs[1]), "--spot_list", spots], capture_output=True, text=True, timeout=300)
+    env = dict(os.environ, RTD_DUMP_CALL=str(tmp_path / "spots.call"))
+    r = subprocess.run(base + ["--output_directory", str(outs[1]), "--spot_list", spots], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr
     assert "3267 spots in 3 layer(s) on a 33x33 spot grid" in r.stdout
+    assert "Total global execution time (excluding GPU initialisation):" in r.stdout
+    # f2 against the oracle: the spot-list run
+    _against_oracle(orc, synth, str(tmp_path / "spots.call"), str(outs[1] / "dose.dat"), 256.0 / 64)
     a = np.fromfile(str(outs[0] / "dose.dat"), dtype=np.float32)
     b = np.fromfile(str(outs[1] / "dose.dat"), dtype=np.float32)
     assert a.max() > 0
