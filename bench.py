@@ -148,6 +148,7 @@ def main():
     main_stream.synchronize()
     step_no = [0]
     in_flight = []                      # (step index, field) launched, not yet finished
+    last_writer = {}                    # dose volume index -> the field object whose last plan wrote into it
 
     def launch():
         """Launch one plan iteration (asynchronous). N=1: fresh dose volume + all kernels of the field. N>1: this rank's field up to
@@ -160,9 +161,11 @@ def main():
             if streams is not None:
                 eng.set_stream(streams[i % n_streams].cuda_stream)
             # fresh dose volume: only the voxels the previous plan wrote are cleared (rtd_field_clear_dose), not all 512^3
-            if i >= len(doses):
-                f.clear_dose(d.data_ptr())
+            v = i % len(doses)
+            if v in last_writer:
+                last_writer[v].clear_dose(d.data_ptr())
             f.compute(d.data_ptr())
+            last_writer[v] = f
         else:
             b = i % 2
             if i >= 2:

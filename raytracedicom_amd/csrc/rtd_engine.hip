@@ -87,6 +87,7 @@ struct rtd_field_impl {
     LayerPlan* dLayers = nullptr;
     float* dStepTab = nullptr;
     int* dActive = nullptr;      // [L][S][4] minima of (x, y, -x, -y) over rays with dose > 0
+    long long* dFillDbg = nullptr; size_t fillDbgN = 0;   // RTD_FILL_DEBUG: per-block clock stamps of k_fill (diagnostics)
     FieldState* dState = nullptr;
     FieldState* hState = nullptr;      // pinned host mirror of *dState (written by k_ks_plan), and its device-side address
     FieldState* dHostState = nullptr;
@@ -383,7 +384,7 @@ int rtd_field_destroy(rtd_handle hh, rtd_field ff) {
     (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = { f->dSpotWeights, f->dConvInterm, f->dRayWeights, f->dDensity, f->dWepl, f->dRrl, f->dIdd, f->dRSigma, f->dBev, f->dBevPart,
                      f->dFirstInside, f->dFirstOutside, f->dFirstPassive, f->dWeplMin, f->dTileRad,
-                     f->dLayers, f->dState, f->dStepTab, f->dActive };
+                     f->dLayers, f->dState, f->dStepTab, f->dActive, f->dFillDbg };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (f->hState) (void)hipHostFree(f->hState);
     for (auto& e : f->ev) if (e) (void)hipEventDestroy(e);
@@ -616,14 +617,18 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
         const size_t fillLds = (size_t)(2 * h->lut.nSamples) * sizeof(float);   // the layer's two cumulative-IDD rows
         const dim3 fillGrid(2 * rayGrid.x * rayGrid.y * fc.L);          // (layer, tile, role) items: sigma walk and dose walk of every tile; placement is decided in the kernel
         const dim3 fillBlk = blk;
+        if (!f->dFillDbg && std::getenv("RTD_FILL_DEBUG")) {
+            f->fillDbgN = (size_t)4 * fillGrid.x;
+            RTD_HIP(h, hipMalloc((void**)&f->dFillDbg, f->fillDbgN * sizeof(long long)));
+        }
         if (fillLds <= 40 * 1024)     // + ~17 KiB of static exchange arrays: stays under the 64 KiB default cap of a block's LDS
             launchK((k_fill<true>), fillGrid, fillBlk, fillLds, s, nullptr, ev(3), (const float*)f->dDensity, (const float*)f->dWepl, (const float*)f->dRrl, f->dIdd,
                                   f->dRSigma, (const float*)f->dRayWeights, (const int*)f->dFirstInside, (const int*)f->dFirstOutside,
-                                  f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc, (const float*)f->dStepTab, f->dActive, h->numCUs);
+                                  f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc, (const float*)f->dStepTab, f->dActive, h->numCUs, f->dFillDbg);
         else
             launchK((k_fill<false>), fillGrid, fillBlk, 0, s, nullptr, ev(3), (const float*)f->dDensity, (const float*)f->dWepl, (const float*)f->dRrl, f->dIdd,
                                   f->dRSigma, (const float*)f->dRayWeights, (const int*)f->dFirstInside, (const int*)f->dFirstOutside,
-                                  f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc, (const float*)f->dStepTab, f->dActive, h->numCUs);
+                                  f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc, (const float*)f->dStepTab, f->dActive, h->numCUs, f->dFillDbg);
     }
     launchK(k_ks_plan, dim3(1), dim3(64), 0, s, nullptr, f->ev[4], f->dState, f->dLayers, fc, f->rayIdxToDoseIdx, f->transfer0,
                           (int)f->doseDims[0], (int)f->doseDims[1], (int)f->doseDims[2], f->ksGroups, f->dHostState);
@@ -837,6 +842,7 @@ int rtd_field_fetch(rtd_handle hh, rtd_field ff, const char* name, void* host_ou
     else if (nm == "first_passive") { src = f->dFirstPassive; n = 4 * R * L; }
     else if (nm == "tile_radius") { src = f->dTileRad; n = L * S * tiles; }
     else if (nm == "bev") { src = f->dBev; n = 4 * (size_t)fc.bevW * fc.bevH * S; }
+    else if (nm == "fill_debug" && f->dFillDbg) { src = f->dFillDbg; n = f->fillDbgN * sizeof(long long); }
     else if (nm == "eff_radius" || nm == "layer_plan") {
         std::vector<LayerPlan> lp(L);
         RTD_HIP(h, hipMemcpy(lp.data(), f->dLayers, L * sizeof(LayerPlan), hipMemcpyDeviceToHost));

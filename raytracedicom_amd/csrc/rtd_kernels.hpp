@@ -63,7 +63,7 @@ struct FieldState {
     // slice = slice slabFirst of the buffer. The field's own BEV buffer: (0, 0, bevW, bevH, beamFirstInside); a slab exported
     // by k_pack_bev for another GPU: the rectangle that carries dose, slices from 0.
     int packX0, packY0, packW, packH, slabFirst;
-    unsigned char fillOrder[256];           // energy layers by ascending number of steps to walk (k_plan), for k_fill's block placement
+    unsigned short fillItems[2 * 256];      // (layer << 1 | role) of k_fill's walks by descending cost (k_plan), for its block placement
     unsigned char tileOrder[kKsMaxOrder];   // superposition dispatch order of the output tiles: most source rays in reach first
 };
 
@@ -459,12 +459,13 @@ __global__ void k_plan(FieldState* st, LayerPlan* layers, const int* weplMinBits
         p.afterLast = (int)(localAfterLast < g ? localAfterLast : g);
     }
     __syncthreads();
-    // layers ranked by the number of steps k_fill walks for them (stable rank by counting; L <= 256)
-    for (int l = threadIdx.x; l < fc.L; l += blockDim.x) {
-        const int a = layers[l].afterLast;
+    // k_fill's walks — (layer, role): role 0 the sigma walk, role 1 the dose walk — ranked by descending cost: steps of the layer x
+    // a measured per-step weight of the role (155 : 100). Stable rank by counting; 2 L <= 512 entries.
+    for (int p = threadIdx.x; p < 2 * fc.L; p += blockDim.x) {
+        const int a = layers[p >> 1].afterLast * ((p & 1) ? 100 : 155);
         int rank = 0;
-        for (int u = 0; u < fc.L; ++u) { const int au = layers[u].afterLast; rank += (au < a || (au == a && u < l)) ? 1 : 0; }
-        st->fillOrder[rank] = (unsigned char)l;
+        for (int u = 0; u < 2 * fc.L; ++u) { const int au = layers[u >> 1].afterLast * ((u & 1) ? 100 : 155); rank += (au > a || (au == a && u < p)) ? 1 : 0; }
+        st->fillItems[rank] = (unsigned short)p;
     }
 }
 
@@ -560,27 +561,32 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
                                                const int* __restrict__ firstOutside, int* __restrict__ firstPassive,
                                                unsigned char* __restrict__ tileRad, LayerPlan* layers, FieldState* st,
                                                LutView lut, FillGeom fg, FieldConst fc, const float* __restrict__ stepTab,
-                                               int* __restrict__ active, int nCU) {
+                                               int* __restrict__ active, int nCU, long long* __restrict__ dbg) {
     extern __shared__ float sLutF[];                                 // dose walk: the layer's two cumulative-IDD rows
+    // diagnostic build only (RTD_FILL_DEBUG): per block start / end clock, hardware id, item — no output value depends on it
+    const long long dbgT0 = dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
     __shared__ float sSig[2][kFillBatch][256];                       // sigma walk: [buffer][step][ray] sigmaSq of the rays with a finite 1/sigma (-1: none)
     __shared__ unsigned long long sDoseMask[2][kFillBatch][4];       // dose walk: [buffer][step][wave] ballot of the rays that carry dose
     __shared__ int sHist[kMaxSuperpR + 2];
 
-    // Block placement. The number of steps differs per layer (150..210 on C3) and a sigma walk is about twice a dose walk,
-    // while only 2*L*tiles blocks exist (5.2 per CU on C3): with a plain grid the CUs that receive the long items set the
-    // kernel time and the others idle. When all blocks are co-resident the dispatcher places block b on CU b % nCU (measured),
-    // so the items, taken in ascending order of cost (layers by steps; per layer the dose walks, then the sigma walks), are
-    // dealt so that the CUs with one block more get the shortest items. (Performance only: any placement gives the same result.)
+    // Block placement. The walks differ in cost — the number of steps per layer (150..210 on C3), and a sigma walk is ~1.5 dose
+    // walks — while only 2*L*tiles blocks exist (5.2 per CU on C3), so a plain grid leaves the kernel waiting for the CUs that
+    // happened to receive the long walks (measured with per-block clock stamps: a CU with five sigma walks of the longest layers
+    // took 430 k cycles, one with five dose walks 200 k). When all blocks are co-resident the dispatcher places block b on CU
+    // b % nCU (measured: blocks b and b + nCU always share a CU), so the walks, taken in descending order of cost (k_plan), are
+    // dealt in rounds of nCU that alternate direction — a CU that got an expensive walk in one round gets a cheap one in the
+    // next — with the direction chosen so that the last, partial round (the cheapest walks) lands on the CUs that received the
+    // cheapest walks of the last full round. (Performance only: any placement gives the same result.)
     const int nTiles = fc.tilesX * fc.tilesY, nB = 2 * nTiles * fc.L;
     int item = blockIdx.x;
     if (nB <= 6 * nCU) {
-        const int q = nB / nCU, r = nB - q * nCU, c = blockIdx.x % nCU, rr = blockIdx.x / nCU;
-        item = c < r ? (q + 1) * c + rr : (q + 1) * r + q * (c - r) + rr;
-    } else {
-        item = nB - 1 - item;                                        // many rounds of blocks: longest first
+        const int rr = blockIdx.x / nCU, c = blockIdx.x % nCU, nFull = nB / nCU;
+        const bool reversed = rr < nFull && ((nFull - 1 - rr) & 1) == 0;       // the last full round: CU 0 gets its cheapest walk
+        item = rr * nCU + (reversed ? nCU - 1 - c : c);
     }
-    const int layer = st->fillOrder[item / (2 * nTiles)];
-    const int role = (item % (2 * nTiles)) < nTiles ? 1 : 0;         // block-uniform: 0 sigma walk, 1 dose walk
+    const int pr = st->fillItems[item / nTiles];
+    const int layer = pr >> 1;
+    const int role = pr & 1;                                         // block-uniform: 0 sigma walk, 1 dose walk
     const int tileNo = item % nTiles, tileX = tileNo % fc.tilesX, tileY = tileNo / fc.tilesX;
     const int tid = threadIdx.y * 32 + threadIdx.x;                  // ray of the tile
     const int wave = tid >> 6;
@@ -775,6 +781,13 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
             }
         }
         if ((tid & 31) < 4 && actUni != 0x7fffffff) atomicMin(&st->actUnion[tid & 3], actUni);
+    }
+    if (dbg && tid == 0) {
+        long long* q = dbg + 4 * (size_t)blockIdx.x;
+        q[0] = dbgT0; q[1] = (long long)__builtin_amdgcn_s_memtime();
+        q[2] = ((long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32) | (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+        q[3] = ((long long)item << 8) | (long long)(role << 4) | 0;
+        (void)pAfterLast;
     }
 }
 
@@ -1406,7 +1419,7 @@ __global__ __launch_bounds__(256) void k_clear_box(float* __restrict__ dose, int
 // bytes][slices x rows x columns]. The receiver runs k_transfer / k_transfer_t straight on the message (the header IS its
 // state record, with the slab geometry rewritten), restricted to its own slab of the dose volume. The BEV block of a 512^3 field
 // is ~10 MB against 60-83 MB for the dose box it turns into: the exchange of a multi-GPU plan is done in beam's-eye view.
-constexpr int kPackHeader = 2048;
+constexpr int kPackHeader = 4096;
 static_assert(sizeof(FieldState) <= kPackHeader, "the state record must fit the message header");
 __global__ __launch_bounds__(256) void k_pack_bev(const float* __restrict__ bevDose, const FieldState* __restrict__ st, FieldConst fc,
                                                    unsigned char* __restrict__ msg, size_t capacity) {
