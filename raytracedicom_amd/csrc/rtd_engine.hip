@@ -82,6 +82,7 @@ struct rtd_field_impl {
     float *dSpotWeights = nullptr, *dConvInterm = nullptr, *dRayWeights = nullptr;
     float *dDensity = nullptr, *dWepl = nullptr, *dRrl = nullptr, *dIdd = nullptr, *dRSigma = nullptr, *dBev = nullptr, *dBevPart = nullptr;
     int *dFirstInside = nullptr, *dFirstOutside = nullptr, *dFirstPassive = nullptr, *dWeplMin = nullptr;
+    float* dBlockWeplMin = nullptr;   // [R/64][S] per scan block and step: smallest WEPL of the block's 64 rays
     unsigned char* dTileRad = nullptr;
     size_t tileRadWords = 0;
     LayerPlan* dLayers = nullptr;
@@ -383,7 +384,7 @@ int rtd_field_destroy(rtd_handle hh, rtd_field ff) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = { f->dSpotWeights, f->dConvInterm, f->dRayWeights, f->dDensity, f->dWepl, f->dRrl, f->dIdd, f->dRSigma, f->dBev, f->dBevPart,
-                     f->dFirstInside, f->dFirstOutside, f->dFirstPassive, f->dWeplMin, f->dTileRad,
+                     f->dFirstInside, f->dFirstOutside, f->dFirstPassive, f->dWeplMin, f->dBlockWeplMin, f->dTileRad,
                      f->dLayers, f->dState, f->dStepTab, f->dActive, f->dFillDbg };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (f->hState) (void)hipHostFree(f->hState);
@@ -524,7 +525,7 @@ static int createField(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dim
         f->dSpotWeights = husk->dSpotWeights; f->dConvInterm = husk->dConvInterm; f->dRayWeights = husk->dRayWeights;
         f->dDensity = husk->dDensity; f->dWepl = husk->dWepl; f->dRrl = husk->dRrl; f->dIdd = husk->dIdd; f->dRSigma = husk->dRSigma;
         f->dBev = husk->dBev; f->dBevPart = husk->dBevPart; f->dFirstInside = husk->dFirstInside; f->dFirstOutside = husk->dFirstOutside;
-        f->dFirstPassive = husk->dFirstPassive; f->dWeplMin = husk->dWeplMin; f->dTileRad = husk->dTileRad; f->dLayers = husk->dLayers;
+        f->dFirstPassive = husk->dFirstPassive; f->dWeplMin = husk->dWeplMin; f->dBlockWeplMin = husk->dBlockWeplMin; f->dTileRad = husk->dTileRad; f->dLayers = husk->dLayers;
         f->dState = husk->dState; f->dStepTab = husk->dStepTab; f->dActive = husk->dActive; f->hState = husk->hState; f->dHostState = husk->dHostState;
         for (int i = 0; i < 9; ++i) f->ev[i] = husk->ev[i];
         delete husk;
@@ -534,7 +535,7 @@ static int createField(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dim
     auto A = [&](auto** p, size_t n) { if (st == RTD_OK && fresh) st = devAlloc(h, p, n); };
     A(&f->dSpotWeights, nSpot); A(&f->dConvInterm, (size_t)W * b->spot_ny * L); A(&f->dRayWeights, R * L);
     A(&f->dDensity, R * S); A(&f->dWepl, R * S); A(&f->dRrl, R * S); A(&f->dIdd, R * S * L); A(&f->dRSigma, R * S * L); A(&f->dBev, P * S); A(&f->dBevPart, P * S * f->ksGroups);
-    A(&f->dFirstInside, R); A(&f->dFirstOutside, R); A(&f->dFirstPassive, R * L); A(&f->dWeplMin, (size_t)S);
+    A(&f->dFirstInside, R); A(&f->dFirstOutside, R); A(&f->dFirstPassive, R * L); A(&f->dWeplMin, (size_t)S); A(&f->dBlockWeplMin, (R / 64) * (size_t)S);
     A(&f->dTileRad, f->tileRadWords * 4); A(&f->dLayers, (size_t)L); A(&f->dState, (size_t)1); A(&f->dStepTab, (size_t)2 * S); A(&f->dActive, (size_t)4 * L * S);
     if (st != RTD_OK) { rtd_field_destroy(hh, reinterpret_cast<rtd_field>(f)); return st; }
     hipError_t e = hipMemcpy(f->dSpotWeights, b->spot_weights, nSpot * sizeof(float), hipMemcpyHostToDevice);   // :851
@@ -583,8 +584,6 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
     // Stage boundaries are the start / stop timestamps of the kernels themselves (hipExtLaunchKernelGGL), not event
     // packets between them: no barrier packet and no idle gap is inserted into the stream by the timing.
     auto ev = [&](int i) -> hipEvent_t { return timing ? f->ev[i] : nullptr; };
-    launchK(k_reset, dim3(64), dim3(256), 0, s, f->ev[0], nullptr, f->dState, f->dLayers, fc.L,
-                          reinterpret_cast<unsigned int*>(f->dTileRad), f->tileRadWords, f->dActive, (size_t)4 * fc.L * fc.S);
     const size_t lutLds = (size_t)(h->lut.nDensity + h->lut.nSp) * sizeof(float);
     // dIdd doubles as the HU scratch of the tracer (it is written by k_fill only afterwards)
     const size_t tLds = lutLds + (size_t)3 * kTrRays * kTrPitch * sizeof(float);
@@ -595,21 +594,23 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
             RTD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_trace_sample_t), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tLds));
             h->traceTLds = tLds;
         }
-        k_trace_sample_t<<<dim3((unsigned)((f->R + kTrRays - 1) / kTrRays)), dim3(64, kTrRays), tLds, s>>>(
-            h->dCt, (int)h->ctDims[0], (int)h->ctDims[1], (int)h->ctDims[2], h->lut, f->tracer, fc.W, fc.H, f->dDensity, f->dWepl, f->dIdd, f->dRrl, h->rrlScale);
+        launchK(k_trace_sample_t, dim3((unsigned)((f->R + kTrRays - 1) / kTrRays)), dim3(64, kTrRays), tLds, s, f->ev[0], nullptr,
+                (const float*)h->dCt, (int)h->ctDims[0], (int)h->ctDims[1], (int)h->ctDims[2], h->lut, f->tracer, fc.W, fc.H, f->dDensity, f->dWepl, f->dIdd,
+                f->dRrl, h->rrlScale, f->dState);
     } else {
-        k_trace_sample<<<dim3((unsigned)(f->R / 256), (fc.S + kTraceSeg - 1) / kTraceSeg), 256, lutLds, s>>>(
-            h->dCt, (int)h->ctDims[0], (int)h->ctDims[1], (int)h->ctDims[2], h->lut, f->tracer, fc.W, fc.H, f->dDensity, f->dWepl, f->dIdd, f->dRrl, h->rrlScale);
+        launchK(k_trace_sample, dim3((unsigned)(f->R / 256), (fc.S + kTraceSeg - 1) / kTraceSeg), dim3(256), lutLds, s, f->ev[0], nullptr,
+                (const float*)h->dCt, (int)h->ctDims[0], (int)h->ctDims[1], (int)h->ctDims[2], h->lut, f->tracer, fc.W, fc.H, f->dDensity, f->dWepl, f->dIdd,
+                f->dRrl, h->rrlScale, f->dState);
     }
     constexpr size_t scanLds = 2 * kScanChunk * 64 * sizeof(float);   // 128 KiB: above the 64 KiB default cap of dynamic LDS
     if (!h->scanLdsSet) {
         RTD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_trace_scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scanLds));
         h->scanLdsSet = true;
     }
-    k_trace_scan<<<(unsigned)(f->R / 64), dim3(64, kScanWaves), scanLds, s>>>(f->dIdd, f->dWepl, fc.W, fc.H, (unsigned)fc.S, f->dFirstInside, f->dFirstOutside,
-                                                     f->dState);
-    launchK(k_slice_min, dim3(fc.S), dim3(256), 0, s, nullptr, ev(1), (const float*)f->dWepl, (size_t)f->R, f->dWeplMin);
-    k_plan<<<1, 64, 0, s>>>(f->dState, f->dLayers, f->dWeplMin, fc);
+    const ResetJob resetJob{f->dLayers, fc.L, reinterpret_cast<unsigned int*>(f->dTileRad), f->tileRadWords, f->dActive, (size_t)4 * fc.L * fc.S};
+    launchK(k_trace_scan, dim3((unsigned)(f->R / 64)), dim3(64, kScanWaves), scanLds, s, nullptr, ev(1), (const float*)f->dIdd, f->dWepl, fc.W, fc.H,
+            (unsigned)fc.S, f->dFirstInside, f->dFirstOutside, f->dState, f->dBlockWeplMin, resetJob);
+    k_plan<<<1, 1024, 0, s>>>(f->dState, f->dLayers, (const float*)f->dBlockWeplMin, (int)(f->R / 64), f->dWeplMin, fc);
     k_conv_x<<<dim3(fc.W / 32, (fc.spotNy + 7) / 8, fc.L), blk, 0, s>>>(f->dSpotWeights, f->dConvInterm, f->dLayers, f->dState, fc);
     launchK(k_conv_y, dim3(fc.W / 32, fc.H / 8, fc.L), blk, 0, s, nullptr, ev(2), (const float*)f->dConvInterm, f->dRayWeights,
                           (const LayerPlan*)f->dLayers, (const FieldState*)f->dState, fc);
@@ -630,7 +631,7 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
                                   f->dRSigma, (const float*)f->dRayWeights, (const int*)f->dFirstInside, (const int*)f->dFirstOutside,
                                   f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc, (const float*)f->dStepTab, f->dActive, h->numCUs, f->dFillDbg);
     }
-    launchK(k_ks_plan, dim3(1), dim3(64), 0, s, nullptr, f->ev[4], f->dState, f->dLayers, fc, f->rayIdxToDoseIdx, f->transfer0,
+    launchK(k_ks_plan, dim3(1), dim3(256), 0, s, nullptr, f->ev[4], f->dState, f->dLayers, fc, f->rayIdxToDoseIdx, f->transfer0,
                           (int)f->doseDims[0], (int)f->doseDims[1], (int)f->doseDims[2], f->ksGroups, f->dHostState);
     {
         const int nTX = (fc.bevW + kKsTileX - 1) / kKsTileX, nTY = (fc.bevH + kKsTileY - 1) / kKsTileY;

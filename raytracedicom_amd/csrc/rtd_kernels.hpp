@@ -177,24 +177,29 @@ __device__ inline float sample3dBorder(const float* __restrict__ vol, int nx, in
 }
 
 // ------------------------------------------------------------------------------------------------
-// K0: reset the per-field device state (the reference re-creates these per beam, kernel_wrapper.cu:685-734).
-__global__ void k_reset(FieldState* st, LayerPlan* layers, int L, unsigned int* __restrict__ tileRadWords, size_t nRadWords,
-                        int* __restrict__ active, size_t nActive) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nT = (size_t)gridDim.x * blockDim.x;
-    if (t == 0) {
-        st->beamFirstInside = 0x7fffffff; st->beamFirstOutside = -0x7fffffff; st->firstGuaranteedPassive = 0;
-        st->firstCalculatedPassive = 0; st->errorFlags = 0; st->maxRadius = 0; st->liveSteps = 0;
-        st->empty = 0;
-        for (int i = 0; i < 4; ++i) st->actUnion[i] = 0x7fffffff;
-        for (int i = 0; i < 3; ++i) { st->bboxMin[i] = 0; st->bboxMax[i] = 0; st->tboxMin[i] = 0; st->tboxMax[i] = -1; }
+// K0: reset of the per-field device state (the reference re-creates these per beam, kernel_wrapper.cu:685-734). No launch of
+// its own: the scalars that the tracer's scan accumulates into are reset by the first thread of the sampling kernel (the
+// launch before the scan), the per-layer records and the two fills that the reference does with cudaMemset per layer
+// (kernel_wrapper.cu:824-827) by the waves of the scan kernel that have no serial chain to walk.
+__device__ inline void resetFieldScalars(FieldState* st) {
+    st->beamFirstInside = 0x7fffffff; st->beamFirstOutside = -0x7fffffff; st->firstGuaranteedPassive = 0;
+    st->firstCalculatedPassive = 0; st->errorFlags = 0; st->maxRadius = 0; st->liveSteps = 0;
+    st->empty = 0;
+    for (int i = 0; i < 4; ++i) st->actUnion[i] = 0x7fffffff;
+    for (int i = 0; i < 3; ++i) { st->bboxMin[i] = 0; st->bboxMax[i] = 0; st->tboxMin[i] = 0; st->tboxMax[i] = -1; }
+}
+struct ResetJob {
+    LayerPlan* layers; int L;
+    unsigned int* tileRadWords; size_t nRadWords;
+    int* active; size_t nActive;
+};
+__device__ inline void resetFieldArrays(const ResetJob& j, size_t t, size_t nT) {
+    for (size_t l = t; l < (size_t)j.L; l += nT) {
+        j.layers[l].layerFirstPassive = 0; j.layers[l].afterLast = 0;
+        for (int i = 0; i < kMaxSuperpR + 2; ++i) { j.layers[l].hist[i] = 0; j.layers[l].effRad[i] = i; }
     }
-    for (size_t l = t; l < (size_t)L; l += nT) {
-        layers[l].layerFirstPassive = 0; layers[l].afterLast = 0;
-        for (int i = 0; i < kMaxSuperpR + 2; ++i) { layers[l].hist[i] = 0; layers[l].effRad[i] = i; }
-    }
-    // (the two fills the reference does with cudaMemset per layer, kernel_wrapper.cu:824-827, in the same launch)
-    for (size_t i = t; i < nRadWords; i += nT) tileRadWords[i] = 0xFFFFFFFFu;      // every (layer, step, tile): "not classified"
-    for (size_t i = t; i < nActive; i += nT) active[i] = 0x7f7f7f7f;               // empty dose rectangles (+large minima)
+    for (size_t i = t; i < j.nRadWords; i += nT) j.tileRadWords[i] = 0xFFFFFFFFu;    // every (layer, step, tile): "not classified"
+    for (size_t i = t; i < j.nActive; i += nT) j.active[i] = 0x7f7f7f7f;             // empty dose rectangles (+large minima)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -213,11 +218,12 @@ constexpr int kTraceSeg = 8;
 __global__ __launch_bounds__(256) void k_trace_sample(const float* __restrict__ ct, int nx, int ny, int nz, LutView lut,
                                                        TracerParams tp, int W, int H, float* __restrict__ bevDensity,
                                                        float* __restrict__ spTerm, float* __restrict__ huBuf,
-                                                       float* __restrict__ bevRrl, float rRlScale) {
+                                                       float* __restrict__ bevRrl, float rRlScale, FieldState* st) {
     extern __shared__ float sLut[];
     float* sDensity = sLut;
     float* sSp = sLut + lut.nDensity;
     const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) resetFieldScalars(st);     // (the scan, next launch, accumulates into them)
     const int ray = blockIdx.x * 256 + tid;
     const int x = ray % W, y = ray / W;
     const size_t memStep = (size_t)W * H;
@@ -268,12 +274,13 @@ constexpr int kTrRays = 16, kTrSteps = 512, kTrPitch = kTrSteps + 4;
 __global__ __launch_bounds__(64 * kTrRays) void k_trace_sample_t(const float* __restrict__ ct, int nx, int ny, int nz, LutView lut,
                                                                   TracerParams tp, int W, int H, float* __restrict__ bevDensity,
                                                                   float* __restrict__ spTerm, float* __restrict__ huBuf,
-                                                                  float* __restrict__ bevRrl, float rRlScale) {
+                                                                  float* __restrict__ bevRrl, float rRlScale, FieldState* st) {
     extern __shared__ float sLut[];
     float* sDensity = sLut;
     float* sSp = sLut + lut.nDensity;
     const int nLut = lut.nDensity + lut.nSp;
     float* tile = sLut + nLut;                                       // [hu, density, sp][kTrRays][kTrPitch]
+    if (blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0) resetFieldScalars(st);
     constexpr int nThreads = 64 * kTrRays;
     const int R = W * H;
     const int lane = threadIdx.x, wv = threadIdx.y, tid = wv * 64 + lane;
@@ -333,11 +340,13 @@ __global__ __launch_bounds__(64 * kTrRays) void k_trace_sample_t(const float* __
 constexpr int kScanWaves = 16, kScanChunk = 256, kScanPerWave = kScanChunk / kScanWaves;
 __global__ __launch_bounds__(64 * kScanWaves) void k_trace_scan(const float* __restrict__ huBuf, float* __restrict__ bevCumulSp, int W, int H,
                                                                  unsigned int steps, int* __restrict__ firstInside, int* __restrict__ firstOutside,
-                                                                 FieldState* st) {
+                                                                 FieldState* st, float* __restrict__ blockWeplMin, ResetJob reset) {
     extern __shared__ float sScan[];                                 // [hu, sp][kScanChunk][64]; the next chunk waits in registers
     const int lane = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
     const int ray = blockIdx.x * 64 + lane;
     const size_t memStep = (size_t)W * H;
+    // the waves without a serial chain reset the per-layer records, the tile-radius bytes and the dose rectangles (K0)
+    if (wv >= 3) resetFieldArrays(reset, ((size_t)blockIdx.x * (kScanWaves - 3) + (wv - 3)) * 64 + lane, (size_t)gridDim.x * (kScanWaves - 3) * 64);
     auto sHu = [&](int, int i) -> float& { return sScan[i * 64 + lane]; };
     auto sSp = [&](int, int i) -> float& { return sScan[(kScanChunk + i) * 64 + lane]; };
     float rHu[kScanPerWave], rSp[kScanPerWave];
@@ -395,7 +404,14 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_trace_scan(const float* __r
 #pragma unroll
         for (int j = 0; j < kScanPerWave; ++j) {                     // all waves store the chunk's WEPL
             const unsigned int i = c0 + wv * kScanPerWave + j;
-            if (i < steps) bevCumulSp[ray + (size_t)i * memStep] = sSp(buf, wv * kScanPerWave + j);
+            if (i < steps) {
+                const float wepl = sSp(buf, wv * kScanPerWave + j);
+                bevCumulSp[ray + (size_t)i * memStep] = wepl;
+                // sliceMinVar<float> (kernel_wrapper.cuh:215-244, launch kernel_wrapper.cu:788), first level: this block's 64 rays;
+                // k_plan takes the minimum over the blocks (one value per block and step instead of a pass over all of WEPL)
+                const float m = waveMin(wepl);
+                if (lane == 0) blockWeplMin[(size_t)blockIdx.x * steps + i] = m;
+            }
         }
         if (c0 + kScanChunk < steps) {
             __syncthreads();                                         // chunk stored: the buffer takes the next one
@@ -414,28 +430,42 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_trace_scan(const float* __r
     }
 }
 
-// sliceMinVar<float> (kernel_wrapper.cuh:215-244, launch kernel_wrapper.cu:788): smallest WEPL of every step.
-// One block per step; unlike the reference there is no n >= blockSize assumption.
-__global__ __launch_bounds__(256) void k_slice_min(const float* __restrict__ bevCumulSp, size_t n, int* __restrict__ weplMinBits) {
-    __shared__ float sM[4];
-    const float* p = bevCumulSp + (size_t)blockIdx.x * n;
-    float m = __int_as_float(0x7f800000);
-    for (size_t i = threadIdx.x; i < n; i += 256) { float t = p[i]; m = t < m ? t : m; }
-    m = waveMin(m);
-    if ((threadIdx.x & (kWave - 1)) == 0) sM[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        m = sM[0]; m = sM[1] < m ? sM[1] : m; m = sM[2] < m ? sM[2] : m; m = sM[3] < m ? sM[3] : m;
-        weplMinBits[blockIdx.x] = __float_as_int(m);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // K2: device-side plan = the host cut-off logic of kernel_wrapper.cu:784,792-802,829-849,923-924.
-__global__ void k_plan(FieldState* st, LayerPlan* layers, const int* weplMinBits, FieldConst fc) {
-    const float* weplMin = reinterpret_cast<const float*>(weplMinBits);
+__global__ __launch_bounds__(1024) void k_plan(FieldState* st, LayerPlan* layers, const float* __restrict__ blockWeplMin, int nScanBlocks,
+                                               int* __restrict__ weplMinBits, FieldConst fc) {
+    __shared__ float weplMin[kMaxSteps];
+    __shared__ float sPart[4][512];          // partial minima (steps <= 512: 2 or 4 threads per step)
     __shared__ int sGuaranteed;
     __shared__ float sEntryZ;
+    // sliceMinVar<float>, second level: smallest WEPL of every step over the scan's blocks. blockWeplMin is [block][step]: thread =
+    // step (coalesced), the blocks split over up to 4 threads per step, 16 loads in flight per thread (a dependent load here is a
+    // full round trip of a single workgroup: the launch is latency, not bandwidth).
+    {
+        const int nParts = fc.S <= 256 ? 4 : (fc.S <= 512 ? 2 : 1);
+        const float inf = __int_as_float(0x7f800000);
+        for (int idx = threadIdx.x; idx < fc.S * nParts; idx += blockDim.x) {
+            const int s0 = idx % fc.S, part = idx / fc.S;
+            const int b0 = (int)((long long)nScanBlocks * part / nParts), b1 = (int)((long long)nScanBlocks * (part + 1) / nParts);
+            float m = inf;
+            for (int b = b0; b < b1; b += 16) {
+                float t[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) t[u] = b + u < b1 ? blockWeplMin[(size_t)(b + u) * fc.S + s0] : inf;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) m = t[u] < m ? t[u] : m;
+            }
+            if (nParts == 1) weplMin[s0] = m; else sPart[part][s0] = m;
+        }
+        __syncthreads();
+        for (int s0 = threadIdx.x; s0 < fc.S; s0 += blockDim.x) {
+            float m = nParts == 1 ? weplMin[s0] : sPart[0][s0];
+            for (int part = 1; part < nParts; ++part) { const float t = sPart[part][s0]; m = t < m ? t : m; }
+            weplMin[s0] = m;
+            weplMinBits[s0] = __float_as_int(m);                      // kept for rtd_field_fetch("wepl_min")
+        }
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
         int first = st->beamFirstInside;
         float entryZ = ((float)first) * fc.rayRes[2] + fc.rayOffset[2];
@@ -794,16 +824,27 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
 // ------------------------------------------------------------------------------------------------
 // K6: superposition plan = host batching of radii (kernel_wrapper.cu:965-976) + beamFirstCalculatedPassive
 // (:955-957) + transfer bounding box and shift (:1185-1213), all on the device.
-__global__ void k_ks_plan(FieldState* st, LayerPlan* layers, FieldConst fc, FromFan rayIdxToDoseIdx, TransferParams tp0,
-                          int doseNx, int doseNy, int doseNz, int G, FieldState* __restrict__ hostMirror) {
+__global__ __launch_bounds__(256) void k_ks_plan(FieldState* stGlobal, LayerPlan* layers, FieldConst fc, FromFan rayIdxToDoseIdx, TransferParams tp0,
+                                                 int doseNx, int doseNy, int doseNz, int G, FieldState* __restrict__ hostMirror) {
+    // The state record is completed in LDS and then written out — to device memory and to its pinned host mirror — by all threads,
+    // one dword each per trip: this one-block launch sits on the field's critical path, and both a load of the record behind a
+    // store to it and a serial copy over PCIe by one thread cost microseconds each.
+    __shared__ FieldState sSt;
     __shared__ int sMaxPassive;
     __shared__ int sGroup[32];
     __shared__ int sMaxRad;
     __shared__ unsigned long long sLive;
+    {
+        const unsigned int* src = reinterpret_cast<const unsigned int*>(stGlobal);
+        unsigned int* dst = reinterpret_cast<unsigned int*>(&sSt);
+        for (unsigned int i = threadIdx.x; i < sizeof(FieldState) / 4; i += blockDim.x) dst[i] = src[i];
+    }
     if (threadIdx.x == 0) { sMaxPassive = 0; sMaxRad = 0; sLive = 0ull; }
     if (threadIdx.x < 32) sGroup[threadIdx.x] = 0;
     __syncthreads();
+    FieldState* st = &sSt;
     const int first = st->beamFirstInside;
+    const int au[4] = { st->actUnion[0], st->actUnion[1], st->actUnion[2], st->actUnion[3] };
     for (int l = threadIdx.x; l < fc.L; l += blockDim.x) {
         LayerPlan& p = layers[l];
         int hist[kMaxSuperpR + 2], effRad[kMaxSuperpR + 2];          // one round trip for the histogram, one for the result
@@ -838,13 +879,13 @@ __global__ void k_ks_plan(FieldState* st, LayerPlan* layers, FieldConst fc, From
         // long items. One tile per thread, stable rank by counting.
         __shared__ int sArea[kKsMaxOrder];
         const int nTX = (fc.bevW + kKsTileX - 1) / kKsTileX, nTY = (fc.bevH + kKsTileY - 1) / kKsTileY, n = nTX * nTY;
-        if (n <= kKsMaxOrder) {                                      // blockDim.x == 64 == kKsMaxOrder
+        if (n <= kKsMaxOrder) {                                      // (kKsMaxOrder <= blockDim.x)
             const int rr = min(sMaxRad, kMaxSuperpR), t = threadIdx.x;
             int area = 0;
             if (t < n) {
                 const int ox0 = (t % nTX) * kKsTileX, oy0 = (t / nTX) * kKsTileY;
-                const int w = min(ox0 + 31 + rr, -st->actUnion[2]) - max(ox0 - 32 - rr, st->actUnion[0]) + 1;
-                const int h = min(oy0 - 1 + rr, -st->actUnion[3]) - max(oy0 - 32 - rr, st->actUnion[1]) + 1;
+                const int w = min(ox0 + 31 + rr, -au[2]) - max(ox0 - 32 - rr, au[0]) + 1;
+                const int h = min(oy0 - 1 + rr, -au[3]) - max(oy0 - 32 - rr, au[1]) + 1;
                 area = (w > 0 && h > 0) ? w * h : 0;
                 sArea[t] = area;
             }
@@ -857,19 +898,15 @@ __global__ void k_ks_plan(FieldState* st, LayerPlan* layers, FieldConst fc, From
         }
     }
     if (threadIdx.x == 0) {
+        // (everything is computed in registers from values read once, and stored at the end: a load of *st behind a store to it is
+        //  a full memory round trip, and this thread is the critical path of the launch)
         const int calcPassive = sMaxPassive;
-        st->firstCalculatedPassive = calcPassive;
-        st->maxRadius = sMaxRad;
-        for (int gI = 0; gI < 32; ++gI) st->groupPassive[gI] = sGroup[gI];
-        // a source at ray (x, y) reaches padded BEV pixels (x+32 +- r, y+32 +- r), r <= the largest batch radius
         const int rr = min(sMaxRad, kMaxSuperpR);
-        st->bevLo[0] = st->actUnion[0] + 32 - rr; st->bevLo[1] = st->actUnion[1] + 32 - rr;
-        st->bevHi[0] = -st->actUnion[2] + 32 + rr; st->bevHi[1] = -st->actUnion[3] + 32 + rr;
-        st->liveSteps = (long long)sLive;
-        st->packX0 = 0; st->packY0 = 0; st->packW = fc.bevW; st->packH = fc.bevH; st->slabFirst = first;
+        // a source at ray (x, y) reaches padded BEV pixels (x+32 +- r, y+32 +- r), r <= the largest batch radius
+        const int bevLo[2] = { au[0] + 32 - rr, au[1] + 32 - rr }, bevHi[2] = { -au[2] + 32 + rr, -au[3] + 32 + rr };
         TransferParams tp = tp0;
         tp.globalOffset.z = tp0.globalOffset.z + (-(float)first);   // invertAndShift(..., -beamFirstInside) :1213
-        st->transfer = tp;
+        int bboxMin[3] = {0, 0, 0}, bboxMax[3] = {0, 0, 0}, tboxMin[3] = {0, 0, 0}, tboxMax[3] = {-1, -1, -1};
         if (calcPassive > first) {
             Vec3 maxP = v3(-1.0f, -1.0f, -1.0f), minP = v3(100000.0f, 100000.0f, 100000.0f);
             float xVals[2] = { -(float)kMaxSuperpR, (float)(fc.W + kMaxSuperpR - 1) };
@@ -881,23 +918,23 @@ __global__ void k_ks_plan(FieldState* st, LayerPlan* layers, FieldConst fc, From
                 if (p.x < minP.x) minP.x = p.x; if (p.y < minP.y) minP.y = p.y; if (p.z < minP.z) minP.z = p.z;
             }
             int t;
-            t = (((int)floorf(minP.x)) / 32) * 32; st->bboxMin[0] = t > 0 ? t : 0;
-            t = (int)floorf(minP.y); st->bboxMin[1] = t > 0 ? t : 0;
-            t = (int)floorf(minP.z); st->bboxMin[2] = t > 0 ? t : 0;
-            t = (int)ceilf(maxP.x); st->bboxMax[0] = t < doseNx - 1 ? t : doseNx - 1;
-            t = (int)ceilf(maxP.y); st->bboxMax[1] = t < doseNy - 1 ? t : doseNy - 1;
-            t = (int)ceilf(maxP.z); st->bboxMax[2] = t < doseNz - 1 ? t : doseNz - 1;
+            t = (((int)floorf(minP.x)) / 32) * 32; bboxMin[0] = t > 0 ? t : 0;
+            t = (int)floorf(minP.y); bboxMin[1] = t > 0 ? t : 0;
+            t = (int)floorf(minP.z); bboxMin[2] = t > 0 ? t : 0;
+            t = (int)ceilf(maxP.x); bboxMax[0] = t < doseNx - 1 ? t : doseNx - 1;
+            t = (int)ceilf(maxP.y); bboxMax[1] = t < doseNy - 1 ? t : doseNy - 1;
+            t = (int)ceilf(maxP.z); bboxMax[2] = t < doseNz - 1 ? t : doseNz - 1;
             // The voxels primTransfDiv visits (kernel_wrapper.cu:69-97, launch :1209-1214): its grid starts at minIdx and is rounded up
             // to whole 32 x 8 blocks, clipped by the dose dimensions only — x and y run PAST maxIdx up to the block edge — while z
             // stops at maxIdx.z. Voxels between maxIdx and the block edge do receive dose when the interpolated BEV value there
             // is non-zero (one BEV step beyond the last slice still interpolates against it), so the coverage is kept exactly.
-            const int covMax[3] = { min(st->bboxMin[0] + roundToI(st->bboxMax[0] - st->bboxMin[0] + 1, 32) - 1, doseNx - 1),
-                                    min(st->bboxMin[1] + roundToI(st->bboxMax[1] - st->bboxMin[1] + 1, 8) - 1, doseNy - 1), st->bboxMax[2] };
+            const int covMax[3] = { min(bboxMin[0] + roundToI(bboxMax[0] - bboxMin[0] + 1, 32) - 1, doseNx - 1),
+                                    min(bboxMin[1] + roundToI(bboxMax[1] - bboxMin[1] + 1, 8) - 1, doseNy - 1), bboxMax[2] };
             // the BEV dose is exactly zero outside the padded rectangle [bevLo, bevHi] and outside the slices [first, calcPassive):
             // the image of that block, grown by the interpolation reach (one pixel / one step on every side), bounds the voxels
             // the transfer can change
-            float txVals[2] = { (float)(st->bevLo[0] - 32 - 1), (float)(st->bevHi[0] - 32 + 1) };
-            float tyVals[2] = { (float)(st->bevLo[1] - 32 - 1), (float)(st->bevHi[1] - 32 + 1) };
+            float txVals[2] = { (float)(bevLo[0] - 32 - 1), (float)(bevHi[0] - 32 + 1) };
+            float tyVals[2] = { (float)(bevLo[1] - 32 - 1), (float)(bevHi[1] - 32 + 1) };
             float tzVals[2] = { (float)(first - 1), (float)calcPassive };
             maxP = v3(-1.0f, -1.0f, -1.0f); minP = v3(100000.0f, 100000.0f, 100000.0f);
             for (int zi = 0; zi < 2; ++zi) for (int yi = 0; yi < 2; ++yi) for (int xi = 0; xi < 2; ++xi) {
@@ -909,16 +946,33 @@ __global__ void k_ks_plan(FieldState* st, LayerPlan* layers, FieldConst fc, From
                                 (int)floorf(minP.y) - 1, (int)floorf(minP.z) - 1 };
             const int hi[3] = { (int)ceilf(maxP.x) + 1, (int)ceilf(maxP.y) + 1, (int)ceilf(maxP.z) + 1 };
             for (int i = 0; i < 3; ++i) {
-                st->tboxMin[i] = lo[i] > st->bboxMin[i] ? lo[i] : st->bboxMin[i];
-                st->tboxMax[i] = hi[i] < covMax[i] ? hi[i] : covMax[i];
+                tboxMin[i] = lo[i] > bboxMin[i] ? lo[i] : bboxMin[i];
+                tboxMax[i] = hi[i] < covMax[i] ? hi[i] : covMax[i];
             }
         }
+        st->firstCalculatedPassive = calcPassive;
+        st->maxRadius = sMaxRad;
+        for (int gI = 0; gI < 32; ++gI) st->groupPassive[gI] = sGroup[gI];
+        st->bevLo[0] = bevLo[0]; st->bevLo[1] = bevLo[1]; st->bevHi[0] = bevHi[0]; st->bevHi[1] = bevHi[1];
+        st->liveSteps = (long long)sLive;
+        st->packX0 = 0; st->packY0 = 0; st->packW = fc.bevW; st->packH = fc.bevH; st->slabFirst = first;
+        st->transfer = tp;
+        for (int i = 0; i < 3; ++i) { st->bboxMin[i] = bboxMin[i]; st->bboxMax[i] = bboxMax[i]; st->tboxMin[i] = tboxMin[i]; st->tboxMax[i] = tboxMax[i]; }
     }
-    // The state record is final here (the kernels after this one only read it): thread 0 mirrors it into pinned host
-    // memory, so rtd_field_finish needs no device-to-host copy (a copy on a second stream stalled the compute queue for
-    // ~37 us per field, measured).
+    // The state record is final here (the kernels after this one only read it): all threads write it to device memory and
+    // mirror it into pinned host memory, so rtd_field_finish needs no device-to-host copy (a copy on a second stream stalled
+    // the compute queue for ~37 us per field, measured). Kernel completion makes both copies visible; no fence is needed.
     __syncthreads();
-    if (threadIdx.x == 0 && hostMirror) { __threadfence(); *hostMirror = *st; __threadfence_system(); }
+    {
+        const unsigned int* src = reinterpret_cast<const unsigned int*>(&sSt);
+        unsigned int* dst = reinterpret_cast<unsigned int*>(stGlobal);
+        volatile unsigned int* mir = reinterpret_cast<volatile unsigned int*>(hostMirror);
+        for (unsigned int i = threadIdx.x; i < sizeof(FieldState) / 4; i += blockDim.x) {
+            const unsigned int v = src[i];
+            dst[i] = v;
+            if (hostMirror) mir[i] = v;
+        }
+    }
 }
 
 
