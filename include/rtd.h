@@ -85,6 +85,9 @@ typedef struct rtd_luts {
     int32_t n_rrl_samples;
     float rrl_scale_fact;
     const float* rrl_vector;       /* 1/X0 per unit density vs density*scale */
+    /* NUCLEAR_CORR only (energy_struct.h:33-36, energy_reader.cpp:103-162); may be NULL when options.nuclear_corr == 0 */
+    const float* nuc_weight_matrix;   /* [n_energies*n_energy_samples] fraction of the dose in the nuclear halo        */
+    const float* nuc_sq_sigma_matrix; /* [n_energies*n_energy_samples] squared sigma of the halo, mm^2                  */
 } rtd_luts;
 
 /*
@@ -99,8 +102,19 @@ typedef struct rtd_options {
     float ks_sigma_cutoff;      /* KS_SIGMA_CUTOFF   3.0  */
     float ray_weight_cutoff;    /* RAY_WEIGHT_CUTOFF 1.0  */
     int32_t fine_grained_timing;/* FINE_GRAINED_TIMING: per-stage hipEvent buckets */
-    int32_t reserved[4];
+    int32_t nuclear_corr;       /* NUCLEAR_CORR (OFF): RTD_NUC_* below. CMakeLists.txt:57-69                             */
+    int32_t reserved[3];
 } rtd_options;
+
+/*
+ * NUCLEAR_CORR: a second, broad Gaussian per spot (the nuclear halo) on a grid at spot resolution. The reference ships this
+ * path switched OFF and unfinished: the constants of the variants carry the comment "CORRECT ALL THESE"
+ * (kernel_wrapper.cu:230), and the fill kernel is constructed with a nuclear memory step of 0 (:925, 7th argument), so every
+ * step of a ray overwrites the SAME nuclear voxel (:367-373) and the halo reaches the dose only through BEV slice 0, i.e. only
+ * when the beam starts inside the patient. This engine restates what that code does, quirk included (the primary dose loses the
+ * nuclear fraction; the halo deposit is whatever slice 0 receives); it does not repair it.
+ */
+enum { RTD_NUC_OFF = 0, RTD_NUC_SOUKUP = 1, RTD_NUC_FLUKA = 2, RTD_NUC_GAUSS_FIT = 3 };
 
 /*
  * Per-field timing record; bucket names follow the reference's FINE_GRAINED_TIMING printout
@@ -160,7 +174,8 @@ int rtd_set_options(rtd_handle h, const rtd_options* opt);
 /* LUT upload, replaces the texture set-up (kernel_wrapper.cu:453-537). Arrays are copied. */
 int rtd_set_luts(rtd_handle h, const rtd_luts* luts);
 /* Reads the reference's LUT text layout from a directory (energy_reader.cpp:12-101) and uploads it.
- * water_cube_test != 0 selects radiation_length_inc_water.txt (energy_reader.cpp:77-93). */
+ * water_cube_test != 0 selects radiation_length_inc_water.txt (energy_reader.cpp:77-93). With options.nuclear_corr set (before
+ * this call) the variant's nuclear_weights_and_sigmas_*.txt is read and checked against the IDD table too (:103-162). */
 int rtd_load_luts_dir(rtd_handle h, const char* dir, int water_cube_test);
 
 /* CT upload, replaces cudaMemcpy3D into the 3-D texture (kernel_wrapper.cu:420-451).

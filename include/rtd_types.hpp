@@ -134,10 +134,12 @@ struct EnergyStruct {   // src/energy_struct.h:13-31
     int nDensitySamples = 0; float densityScaleFact = 0; std::vector<float> densityVector;
     int nSpSamples = 0; float spScaleFact = 0; std::vector<float> spVector;
     int nRRlSamples = 0; float rRlScaleFact = 0; std::vector<float> rRlVector;
+    std::vector<float> nucWeightMatrix, nucSqSigmaMatrix;   // NUCLEAR_CORR only (energy_struct.h:33-36); empty otherwise
 };
 
-// energyReader(dataPath) (src/energy_reader.cpp:12-101); waterCubeTest selects the *_inc_water radiation-length file.
-inline EnergyStruct energyReader(const std::string& dataPath, bool waterCubeTest = false) {
+// energyReader(dataPath) (src/energy_reader.cpp:12-162); waterCubeTest selects the *_inc_water radiation-length file, nuclearCorr
+// (RTD_NUC_*, include/rtd.h) the NUCLEAR_CORR table to read and check as well (:103-162).
+inline EnergyStruct energyReader(const std::string& dataPath, bool waterCubeTest = false, int nuclearCorr = 0) {
     EnergyStruct e;
     auto open = [&](const std::string& name) {
         std::ifstream f((dataPath + name).c_str());
@@ -165,6 +167,27 @@ inline EnergyStruct energyReader(const std::string& dataPath, bool waterCubeTest
     one("density_Schneider2000_adj.txt", e.nDensitySamples, e.densityScaleFact, e.densityVector);
     one("HU_to_SP_H&N_adj.txt", e.nSpSamples, e.spScaleFact, e.spVector);
     one(waterCubeTest ? "radiation_length_inc_water.txt" : "radiation_length.txt", e.nRRlSamples, e.rRlScaleFact, e.rRlVector);
+    if (nuclearCorr != RTD_NUC_OFF) {
+        const std::string name = nuclearCorr == RTD_NUC_SOUKUP ? "nuclear_weights_and_sigmas_Soukup.txt"
+                               : nuclearCorr == RTD_NUC_FLUKA ? "nuclear_weights_and_sigmas_Fluka.txt" : "nuclear_weights_and_sigmas_fit.txt";
+        std::ifstream f = open(name);
+        int nS = 0, nE = 0;
+        f >> nS >> nE;
+        if (nS != e.nEnergySamples || nE != e.nEnergies)
+            throw std::runtime_error("Number of samples or energies in " + name + " different from proton_cumul_ddd_data.txt");
+        const std::vector<float>* axes[3] = { &e.energiesPerU, &e.peakDepths, &e.scaleFacts };
+        const char* what[3] = { "Energies", "Peak depths", "Scale facts" };
+        for (int a = 0; a < 3; ++a)
+            for (int i = 0; i < nE; ++i) {
+                float v = 0;
+                f >> v;
+                if (std::fabs((*axes[a])[i] - v) > 0.01f) throw std::runtime_error(std::string(what[a]) + " in " + name + " different from proton_cumul_ddd_data.txt");
+            }
+        e.nucWeightMatrix.resize((size_t)nS * nE); e.nucSqSigmaMatrix.resize((size_t)nS * nE);
+        for (auto& v : e.nucWeightMatrix) f >> v;
+        for (auto& v : e.nucSqSigmaMatrix) f >> v;
+        if (!f) throw std::runtime_error("Truncated " + dataPath + name);
+    }
     return e;
 }
 

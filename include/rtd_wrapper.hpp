@@ -26,6 +26,8 @@
 #include <ostream>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "rtd.h"
@@ -54,9 +56,20 @@ inline rtd_idx_transform toIdx(const Idx& t) {
     return r;
 }
 
+// the NUCLEAR_CORR members exist in the reference's EnergyStruct only when it is built with that option (energy_struct.h:33-36)
+template <class Energy, class = void> struct HasNuclearTables : std::false_type {};
+template <class Energy> struct HasNuclearTables<Energy, decltype((void)std::declval<const Energy&>().nucWeightMatrix, void())> : std::true_type {};
+template <class Energy>
+inline void nuclearTables(const Energy& e, rtd_luts& l, std::true_type) {
+    if (!e.nucWeightMatrix.empty() && !e.nucSqSigmaMatrix.empty()) { l.nuc_weight_matrix = e.nucWeightMatrix.data(); l.nuc_sq_sigma_matrix = e.nucSqSigmaMatrix.data(); }
+}
+template <class Energy>
+inline void nuclearTables(const Energy&, rtd_luts&, std::false_type) {}
+
 template <class Energy>
 inline rtd_luts toLuts(const Energy& e) {
     rtd_luts l{};
+    nuclearTables(e, l, HasNuclearTables<Energy>{});
     l.n_energy_samples = e.nEnergySamples; l.n_energies = e.nEnergies;
     l.energies_per_u = e.energiesPerU.data(); l.peak_depths = e.peakDepths.data(); l.scale_facts = e.scaleFacts.data();
     l.cidd_matrix = e.ciddMatrix.data();

@@ -94,6 +94,46 @@ def g1():
     return arrs  # real_water arrays
 
 
+def g1n():
+    """G1n: the NUCLEAR_CORR part of the LUT parser (energy_reader.cpp:103-162), one reference build per variant."""
+    from raytracedicom_amd import luts
+    out = {}
+    small_dir = os.path.join(GOLD, "lut_small_nuc")
+    es = luts.synth_luts(n_energies=5, n_samples=16, n_hu=12, nuclear=True)
+    luts.write_lut_dir(small_dir, es)
+    # make the three variants' files differ (the reference ships three different tables)
+    for k, name in luts.NUC_FILES.items():
+        es_k = luts.synth_luts(n_energies=5, n_samples=16, n_hu=12, nuclear=True)
+        es_k.nucWeightMatrix *= np.float32(1.0 + 0.1 * k)
+        es_k.nucSqSigmaMatrix += np.float32(k)
+        with open(os.path.join(small_dir, name), "w") as fh:
+            row = lambda a: " ".join(repr(float(x)) for x in np.asarray(a, dtype=np.float32))
+            fh.write("%d %d\n\n" % (es.nEnergySamples, es.nEnergies))
+            fh.write(row(es.energiesPerU) + "\n\n" + row(es.peakDepths) + "\n\n" + row(es.scaleFacts) + "\n\n")
+            for r in es_k.nucWeightMatrix:
+                fh.write(row(r) + "\n")
+            fh.write("\n")
+            for r in es_k.nucSqSigmaMatrix:
+                fh.write(row(r) + "\n")
+    for k, v in ((1, "SOUKUP"), (2, "FLUKA"), (3, "GAUSS_FIT")):
+        L = load("libref_nuc_%s.so" % v)
+        for tag, d in (("small", small_dir + "/"), ("real", REF_LUTS)):
+            assert L.ref_energy_reader(d.encode()) == 0, d
+            for w, nm in ((7, "weight"), (8, "sqsigma")):
+                n = L.ref_energy_size(w)
+                a = np.empty(n, dtype=np.float32)
+                L.ref_energy_copy(w, P(a))
+                if tag == "small":
+                    out["small_%d_%s" % (k, nm)] = a
+                else:
+                    out["real_%d_%s_n" % (k, nm)] = np.int64(n)
+                    out["real_%d_%s_sha256" % (k, nm)] = np.array(sha(a))
+                    out["real_%d_%s_sum64" % (k, nm)] = a.astype(np.float64).sum()
+                    out["real_%d_%s_head" % (k, nm)] = a[:4]
+                    out["real_%d_%s_tail" % (k, nm)] = a[-4:]
+    np.savez(os.path.join(GOLD, "golden_g1n_nuclear_lut.npz"), **out)
+
+
 def g2(real):
     L = load("libref.so")
     energies, peaks, scales = real[0], real[1], real[2]
@@ -165,6 +205,11 @@ def g7():
         out["yscatter%d" % ci] = yo
     np.savez(os.path.join(GOLD, "golden_g7_cpu_conv.npz"), **out)
 
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "g1n":
+    g1n()
+    print("wrote golden_g1n_nuclear_lut.npz")
+    sys.exit(0)
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)

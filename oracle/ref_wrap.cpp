@@ -26,6 +26,9 @@ long ref_energy_size(int which) {
         case 2: return (long)g_es.scaleFacts.size(); case 3: return (long)g_es.ciddMatrix.size();
         case 4: return (long)g_es.densityVector.size(); case 5: return (long)g_es.spVector.size();
         case 6: return (long)g_es.rRlVector.size();
+#ifdef NUCLEAR_CORR
+        case 7: return (long)g_es.nucWeightMatrix.size(); case 8: return (long)g_es.nucSqSigmaMatrix.size();
+#endif
     }
     return -1;
 }
@@ -35,6 +38,9 @@ void ref_energy_copy(int which, float* dst) {
         case 0: v = &g_es.energiesPerU; break; case 1: v = &g_es.peakDepths; break; case 2: v = &g_es.scaleFacts; break;
         case 3: v = &g_es.ciddMatrix; break; case 4: v = &g_es.densityVector; break; case 5: v = &g_es.spVector; break;
         case 6: v = &g_es.rRlVector; break;
+#ifdef NUCLEAR_CORR
+        case 7: v = &g_es.nucWeightMatrix; break; case 8: v = &g_es.nucSqSigmaMatrix; break;
+#endif
     }
     if (v) std::memcpy(dst, v->data(), v->size() * sizeof(float));
 }

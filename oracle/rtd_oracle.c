@@ -531,9 +531,18 @@ static void stage_conv2d(const float* in, float* interm, float* out, const f2* s
 }
 
 /* Stage 3: fillIddAndSigma without NUCLEAR_CORR (kernel_wrapper.cu:190-379). */
+/* The NUCLEAR_CORR arguments of fillIddAndSigma (kernel_wrapper.cu:190-198): arrays on the nuclear (spot-resolution) grid. */
+typedef struct {
+    float* bevNucIdd; float* bevNucRSigmaEff;      /* [S][nucH][nucW], but see nucMemStep */
+    const float* nucRayWeights;                    /* this layer's padded spot weights [nucH][nucW] (extendAndPadd, :51-66) */
+    const int* nucIdcs;                            /* [H][W] index of the ray's spot on the nuclear grid, -1 if none (:878-892) */
+    float spotDist, entrySigmaSq;                  /* FillIddAndSigmaParams::getSpotDist / getEntrySigmaSq */
+    unsigned int nucMemStep;                       /* the reference passes 0 (:925, 7th constructor argument) */
+} nuc_fill;
+
 static void stage_fill(const float* bevDensity, const float* bevCumulSp, float* bevIdd, float* bevRSigmaEff,
                        const float* rayWeights, const int* firstInside, const int* firstOutside, int* firstPassive,
-                       const fill_params* pp, const rtd_luts* l, const rtd_options* opt, int W, int H) {
+                       const fill_params* pp, const rtd_luts* l, const rtd_options* opt, int W, int H, const nuc_fill* nuc) {
     const size_t memStep = (size_t)W * H;
     const fill_params params = *pp;
 #pragma omp parallel for schedule(static)
@@ -548,10 +557,22 @@ static void stage_fill(const float* bevDensity, const float* bevCumulSp, float* 
 
         float res = 0.0f, rSigmaEff = 0.0f, cumulSp, cumulSpOld = 0.0f, cumulDose, cumulDoseOld = 0.0f;
         const float pInv = 0.5649718f, eCoef = 8.639415f, sqrt2 = 1.41421356f;
-        const float eRefSq = 198.81f, sigmaDelta = 0.21f;
+        /* E_s^2 and the empirical widening per NUCLEAR_CORR variant (:228-245; "CORRECT ALL THESE" in the reference) */
+        float eRefSq = 198.81f, sigmaDelta = 0.21f;
+        if (opt->nuclear_corr == RTD_NUC_SOUKUP) { eRefSq = 190.44f; sigmaDelta = 0.0f; }
+        else if (opt->nuclear_corr == RTD_NUC_FLUKA) { eRefSq = 216.09f; sigmaDelta = 0.08f; }
+        else if (opt->nuclear_corr == RTD_NUC_GAUSS_FIT) { eRefSq = 169.00f; sigmaDelta = 0.06f; }
         float incScat = 0.0f, incincScat = 0.0f;
         float incDiv = params.sigmaSqAirLin + (2.0f * (float)params.first - 1.0f) * params.sigmaSqAirQuad;
         float sigmaSq = -incDiv;
+        /* :253-263 */
+        float nucRes = 0.0f, nucRSigmaEff = 0.0f, nucRayWeight = 0.0f;
+        long long nucIdx = -1;
+        if (nuc) {
+            nucIdx = nuc->nucIdcs[idx];
+            if (nucIdx >= 0) nucRayWeight = nuc->nucRayWeights[nucIdx];
+            nucIdx += (long long)params.first * nuc->nucMemStep;
+        }
 
         idx += (size_t)params.first * memStep;
         for (unsigned int stepNo = params.first; stepNo < params.afterLast; ++stepNo) {
@@ -573,7 +594,8 @@ static void stage_fill(const float* bevDensity, const float* bevCumulSp, float* 
                     incScat += incincScat;
                     incDiv += 2.0f * params.sigmaSqAirQuad;
                 } else {
-                    sigmaSq -= 1.5f * (incScat + incDiv) * density;
+                    if (opt->nuclear_corr != RTD_NUC_GAUSS_FIT)                       /* :300-302 */
+                        sigmaSq -= 1.5f * (incScat + incDiv) * density;
                 }
                 f2 vw = fill_voxel_width(&params, stepNo);
                 rSigmaEff = 0.5f * (vw.x + vw.y) / (sqrt2 * (sqrtf(sigmaSq) + sigmaDelta));
@@ -582,13 +604,30 @@ static void stage_fill(const float* bevDensity, const float* bevCumulSp, float* 
                 }
                 float mass = opt->dose_to_water ? (cumulSp - cumulSpOld) * fill_step_vol(&params, stepNo)
                                                 : density * fill_step_vol(&params, stepNo);
-                if (mass > 1e-2f) res = rayWeight * (cumulDose - cumulDoseOld) / mass;
+                if (!nuc) {
+                    if (mass > 1e-2f) res = rayWeight * (cumulDose - cumulDoseOld) / mass;
+                } else {                                                              /* :320-341 */
+                    const float px = 0.5f * (cumulSp + cumulSpOld) * params.energyScaleFact;
+                    if (mass > 1e-2f) {
+                        float nucWeight = sample2d_clamp(l->nuc_weight_matrix, l->n_energy_samples, l->n_energies, px, params.energyIdx);
+                        res = (1.0f - nucWeight) * rayWeight * (cumulDose - cumulDoseOld) / mass;
+                        nucRes = nucWeight * nucRayWeight * (cumulDose - cumulDoseOld) / (mass * nuc->spotDist * nuc->spotDist);
+                    }
+                    if (nucIdx >= 0) {
+                        float nucSqSigma = sample2d_clamp(l->nuc_sq_sigma_matrix, l->n_energy_samples, l->n_energies, px, params.energyIdx);
+                        nucRSigmaEff = 0.5f * nuc->spotDist * (vw.x + vw.y) / (sqrt2 * sqrtf(sigmaSq + nucSqSigma + nuc->entrySigmaSq));
+                    }
+                }
                 cumulSpOld = cumulSp;
                 cumulDoseOld = cumulDose;
             }
-            if (!beamLive || (int)stepNo < (firstIn - 1)) { res = 0.0f; rSigmaEff = INFINITY; }
+            if (!beamLive || (int)stepNo < (firstIn - 1)) { res = 0.0f; rSigmaEff = INFINITY; nucRes = 0.0f; nucRSigmaEff = INFINITY; }
             bevIdd[idx] = res;
             bevRSigmaEff[idx] = rSigmaEff;
+            if (nuc) {                                                                /* :367-374 */
+                if (nucIdx >= 0) { nuc->bevNucIdd[nucIdx] = nucRes; nuc->bevNucRSigmaEff[nucIdx] = nucRSigmaEff; }
+                nucIdx += nuc->nucMemStep;
+            }
             idx += memStep;
         }
         firstPassive[(size_t)y * W + x] = (int)afterLast;
@@ -860,6 +899,7 @@ int orc_field_run(const rtd_luts* l, const float* ct, const uint32_t ctDims[3], 
         float sx = b->spot_sigmas[2 * ln], sy = b->spot_sigmas[2 * ln + 1];
         entrySigmas[ln].x = sqrtf(c.x * entryZ * entryZ + c.y * entryZ + sx * sx);
         entrySigmas[ln].y = sqrtf(c.x * entryZ * entryZ + c.y * entryZ + sy * sy);
+        if (opt->nuclear_corr == RTD_NUC_GAUSS_FIT) { entrySigmas[ln].x = 0.97f * entrySigmas[ln].x; entrySigmas[ln].y = 0.97f * entrySigmas[ln].y; }  /* :842-847 */
     }
     f2 pxSpMult; pxSpMult.x = 1.0f - entryZ / b->source_dist[0]; pxSpMult.y = 1.0f - entryZ / b->source_dist[1];  /* :849 */
 
@@ -871,6 +911,43 @@ int orc_field_run(const rtd_luts* l, const float* ct, const uint32_t ctDims[3], 
                      mk3(rayRes[0], rayRes[1], rayRes[2]), mk3(rayOffset[0], rayOffset[1], rayOffset[2]), pxSpMult,
                      opt->conv_sigma_cutoff);
         free(interm);
+    }
+
+    /* NUCLEAR_CORR set-up (:665-668, 736-751, 858-892): the nuclear grid is the spot grid rounded up to whole tiles */
+    const int nucOn = opt->nuclear_corr != RTD_NUC_OFF;
+    if (nucOn && (!l->nuc_weight_matrix || !l->nuc_sq_sigma_matrix)) {
+        snprintf(f->err, sizeof f->err, "nuclear_corr set but the LUTs carry no nuclear tables");
+        free(energyIdcs); free(energyScaleFacts); free(peakDepths); free(entrySigmas);
+        if (!out) orc_field_free(f);
+        return RTD_ERR_INVALID_ARG;
+    }
+    const int nucW = nucOn ? round_to((int)b->spot_nx, SUPERP_TILE_X) : 0, nucH = nucOn ? round_to((int)b->spot_ny, SUPERP_TILE_Y) : 0;
+    const size_t nucR = (size_t)nucW * nucH, nucIddN = nucR * (size_t)S;
+    const int bevNucW = nucW + 2 * MAX_SUPERP_R, bevNucH = nucH + 2 * MAX_SUPERP_R;
+    float* nucRayWeights = NULL, *nucIdd = NULL, *nucRs = NULL, *bevNuc = NULL;
+    int* nucSpotIdx = NULL;
+    uint8_t* nucTileRad = NULL;
+    if (nucOn) {
+        nucRayWeights = (float*)calloc(nucR * (size_t)L, sizeof(float));                                /* extendAndPadd :51-66 */
+        for (int z = 0; z < L; ++z) for (unsigned int y = 0; y < b->spot_ny; ++y) for (unsigned int x = 0; x < b->spot_nx; ++x)
+            nucRayWeights[(size_t)z * nucR + (size_t)y * nucW + x] = b->spot_weights[((size_t)z * b->spot_ny + y) * b->spot_nx + x];
+        nucIdd = (float*)calloc(nucIddN, sizeof(float));                                                /* :862 */
+        nucRs = (float*)malloc(sizeof(float) * nucIddN);                                                /* :863 */
+        for (size_t i = 0; i < nucIddN; ++i) nucRs[i] = INFINITY;
+        bevNuc = (float*)calloc((size_t)bevNucW * bevNucH * S, sizeof(float));
+        nucTileRad = (uint8_t*)malloc((size_t)S * (nucW / SUPERP_TILE_X) * (nucH / SUPERP_TILE_Y));
+        nucSpotIdx = (int*)malloc(sizeof(int) * R);                                                     /* :878-892 */
+        for (size_t i = 0; i < R; ++i) nucSpotIdx[i] = -1;
+        for (unsigned int sy = 0; sy < b->spot_ny; ++sy) {
+            float gantryPosY = (float)sy * sitg.delta.y + sitg.offset.y;
+            int rayIdxY = (int)roundf((gantryPosY - rayOffset[1]) / rayRes[1]);
+            for (unsigned int sx = 0; sx < b->spot_nx; ++sx) {
+                float gantryPosX = (float)sx * sitg.delta.x + sitg.offset.x;
+                int rayIdxX = (int)roundf((gantryPosX - rayOffset[0]) / rayRes[0]);
+                if (rayIdxX >= 0 && rayIdxX < W && rayIdxY >= 0 && rayIdxY < H)      /* (the reference indexes unchecked) */
+                    nucSpotIdx[(size_t)W * rayIdxY + rayIdxX] = nucW * (int)sy + (int)sx;
+            }
+        }
     }
 
     int status = RTD_OK;
@@ -886,8 +963,15 @@ int orc_field_run(const rtd_luts* l, const float* ct, const uint32_t ctDims[3], 
             float* rs = f->rsigma + (keepLayers ? layerElems * ln : 0);
             uint8_t* tr = f->tileRad + (keepLayers ? tileElems * ln : 0);
             int* fpass = f->firstPassive + R * ln;
+            nuc_fill nf;
+            if (nucOn) {
+                nf.bevNucIdd = nucIdd; nf.bevNucRSigmaEff = nucRs; nf.nucRayWeights = nucRayWeights + nucR * ln; nf.nucIdcs = nucSpotIdx;
+                nf.spotDist = sitg.delta.x / b->ray_spacing[0];                                          /* spotDistInRays :922 */
+                nf.entrySigmaSq = entrySigmas[ln].x * entrySigmas[ln].x;                                  /* :925, 4th argument */
+                nf.nucMemStep = 0;                                                                       /* :925, 7th argument */
+            }
             stage_fill(f->density, f->wepl, idd, rs, f->rayWeights + R * ln, f->firstInside, f->firstOutside, fpass,
-                       &fp, l, opt, W, H);
+                       &fp, l, opt, W, H, nucOn ? &nf : NULL);
             int layerFirstPassive = fpass[0];                                                          /* :952-957 */
             for (size_t i = 1; i < R; ++i) if (fpass[i] > layerFirstPassive) layerFirstPassive = fpass[i];
             if (layerFirstPassive > beamFirstCalculatedPassive) beamFirstCalculatedPassive = layerFirstPassive;
@@ -907,6 +991,17 @@ int orc_field_run(const rtd_luts* l, const float* ct, const uint32_t ctDims[3], 
             if (layerMax > maxRadius) maxRadius = layerMax;
             if (layerFirstPassive > beamFirstInside) liveSteps += layerFirstPassive - beamFirstInside;
             stage_superposition(idd, rs, f->bev, W, H, tr, eff, beamFirstInside, layerFirstPassive);    /* :1024-1056 */
+            if (nucOn) {                                                                                /* :978-997, :1058-1091 */
+                int nctrs[MAX_SUPERP_R + 2], neff[MAX_SUPERP_R + 2];
+                stage_tile_radius(nucRs, nucW, nucH, beamFirstInside, layerFirstPassive, opt->ks_sigma_cutoff, nucTileRad, S, nctrs);
+                if (nctrs[MAX_SUPERP_R + 1] > 0) {
+                    snprintf(f->err, sizeof f->err, "Found larger than allowed kernel superposition radius");
+                    status = RTD_ERR_RADIUS_OVERFLOW;
+                    break;
+                }
+                orc_batch_radii(nctrs, neff);
+                stage_superposition(nucIdd, nucRs, bevNuc, nucW, nucH, nucTileRad, neff, beamFirstInside, layerFirstPassive);
+            }
         }
     }
     f->info.beam_first_calculated_passive = beamFirstCalculatedPassive;
@@ -941,6 +1036,32 @@ int orc_field_run(const rtd_luts* l, const float* ct, const uint32_t ctDims[3], 
             stage_transfer(dose, doseDims, &tps, minIdx, maxIdx, f->bev + (size_t)beamFirstInside * bevW * bevH, bevW, bevH,
                            beamFirstCalculatedPassive - beamFirstInside);
     }
+    /* nuclear transfer (:1221-1254): the halo cube lives on the spot grid -> its own fan transform */
+    if (nucOn && status == RTD_OK && beamFirstCalculatedPassive > beamFirstInside) {
+        fromfan nucRayIdxToDoseIdx = make_fromfan(&b->spot_idx_to_gantry, b->source_dist, &b->gantry_to_dose_idx);
+        f3 maxP = mk3(-1.0f, -1.0f, -1.0f), minP = mk3(100000.0f, 100000.0f, 100000.0f);
+        float xVals[2] = { -(float)MAX_SUPERP_R, (float)(nucW + MAX_SUPERP_R - 1) };
+        float yVals[2] = { -(float)MAX_SUPERP_R, (float)(nucH + MAX_SUPERP_R - 1) };
+        float zVals[2] = { (float)beamFirstInside, (float)(beamFirstCalculatedPassive - 1) };
+        for (int zi = 0; zi < 2; ++zi) for (int yi = 0; yi < 2; ++yi) for (int xi = 0; xi < 2; ++xi) {
+            f3 p = fromfan_point(&nucRayIdxToDoseIdx, mk3(xVals[xi], yVals[yi], zVals[zi]));
+            if (p.x > maxP.x) maxP.x = p.x; if (p.y > maxP.y) maxP.y = p.y; if (p.z > maxP.z) maxP.z = p.z;
+            if (p.x < minP.x) minP.x = p.x; if (p.y < minP.y) minP.y = p.y; if (p.z < minP.z) minP.z = p.z;
+        }
+        int minIdx[3], maxIdx[3], t;
+        t = (((int)floorf(minP.x)) / 32) * 32; minIdx[0] = t > 0 ? t : 0;
+        t = (int)floorf(minP.y); minIdx[1] = t > 0 ? t : 0;
+        t = (int)floorf(minP.z); minIdx[2] = t > 0 ? t : 0;
+        t = (int)ceilf(maxP.x); maxIdx[0] = t < (int)doseDims[0] - 1 ? t : (int)doseDims[0] - 1;
+        t = (int)ceilf(maxP.y); maxIdx[1] = t < (int)doseDims[1] - 1 ? t : (int)doseDims[1] - 1;
+        t = (int)ceilf(maxP.z); maxIdx[2] = t < (int)doseDims[2] - 1 ? t : (int)doseDims[2] - 1;
+        tofan inv = fromfan_invert_and_shift(&nucRayIdxToDoseIdx, mk3((float)MAX_SUPERP_R, (float)MAX_SUPERP_R, -(float)beamFirstInside));
+        transfer_params tps = transfer_params_make(&inv);
+        if (maxIdx[0] >= minIdx[0] && maxIdx[1] >= minIdx[1] && maxIdx[2] >= minIdx[2])
+            stage_transfer(dose, doseDims, &tps, minIdx, maxIdx, bevNuc + (size_t)beamFirstInside * bevNucW * bevNucH, bevNucW, bevNucH,
+                           beamFirstCalculatedPassive - beamFirstInside);
+    }
+    free(nucRayWeights); free(nucIdd); free(nucRs); free(bevNuc); free(nucSpotIdx); free(nucTileRad);
     free(energyIdcs); free(energyScaleFacts); free(peakDepths); free(entrySigmas);
     if (!out) orc_field_free(f);
     return status;
@@ -1069,9 +1190,35 @@ int orc_read_luts(const char* dir, int waterCubeTest, rtd_luts* out) {
     out->rrl_vector = v;
     return RTD_OK;
 }
+/* The NUCLEAR_CORR part of energyReader (energy_reader.cpp:103-162): the variant's table, with the reference's consistency
+ * checks against the cumulative-IDD table. variant: RTD_NUC_*. */
+int orc_read_luts_nuc(const char* dir, int waterCubeTest, int variant, rtd_luts* out) {
+    int rc = orc_read_luts(dir, waterCubeTest, out);
+    if (rc != RTD_OK || variant == RTD_NUC_OFF) return rc;
+    const char* name = variant == RTD_NUC_SOUKUP ? "nuclear_weights_and_sigmas_Soukup.txt"
+                     : variant == RTD_NUC_FLUKA ? "nuclear_weights_and_sigmas_Fluka.txt" : "nuclear_weights_and_sigmas_fit.txt";
+    char path[4096];
+    snprintf(path, sizeof path, "%s%s", dir, name);
+    FILE* fp = fopen(path, "r");
+    if (!fp) return RTD_ERR_IO;
+    int nS = 0, nE = 0;
+    if (fscanf(fp, "%d %d", &nS, &nE) != 2 || nS != out->n_energy_samples || nE != out->n_energies) { fclose(fp); return RTD_ERR_IO; }
+    const float* axes[3] = { out->energies_per_u, out->peak_depths, out->scale_facts };
+    for (int a = 0; a < 3; ++a)
+        for (int i = 0; i < nE; ++i) {
+            float v;
+            if (fscanf(fp, "%f", &v) != 1 || fabsf(axes[a][i] - v) > 0.01f) { fclose(fp); return RTD_ERR_IO; }
+        }
+    float* w = (float*)malloc(sizeof(float) * (size_t)nE * nS), *q = (float*)malloc(sizeof(float) * (size_t)nE * nS);
+    rc = read_floats(fp, w, (size_t)nE * nS) | read_floats(fp, q, (size_t)nE * nS);
+    fclose(fp);
+    out->nuc_weight_matrix = w; out->nuc_sq_sigma_matrix = q;
+    return rc ? RTD_ERR_IO : RTD_OK;
+}
 void orc_luts_free(rtd_luts* l) {
     free((void*)l->energies_per_u); free((void*)l->peak_depths); free((void*)l->scale_facts); free((void*)l->cidd_matrix);
     free((void*)l->density_vector); free((void*)l->sp_vector); free((void*)l->rrl_vector);
+    free((void*)l->nuc_weight_matrix); free((void*)l->nuc_sq_sigma_matrix);
     memset(l, 0, sizeof *l);
 }
 

@@ -66,6 +66,7 @@ void orc_y_conv_cpu(const float* in, float* out, float rSigmaEff, unsigned int r
 
 /* LUT text layout (energy_reader.cpp) */
 int orc_read_luts(const char* dir, int waterCubeTest, rtd_luts* out);
+int orc_read_luts_nuc(const char* dir, int waterCubeTest, int variant, rtd_luts* out);
 void orc_luts_free(rtd_luts* l);
 
 /* gamma index */

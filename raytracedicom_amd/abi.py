@@ -17,6 +17,7 @@ RTD_ERR_RADIUS_OVERFLOW = -3
 RTD_ERR_NOT_READY = -4
 RTD_ERR_IO = -5
 RTD_ERR_NO_DEVICE = -6
+RTD_NUC_OFF, RTD_NUC_SOUKUP, RTD_NUC_FLUKA, RTD_NUC_GAUSS_FIT = 0, 1, 2, 3
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -52,6 +53,7 @@ class RtdLuts(C.Structure):
         ("n_density_samples", C.c_int32), ("density_scale_fact", C.c_float), ("density_vector", c_float_p),
         ("n_sp_samples", C.c_int32), ("sp_scale_fact", C.c_float), ("sp_vector", c_float_p),
         ("n_rrl_samples", C.c_int32), ("rrl_scale_fact", C.c_float), ("rrl_vector", c_float_p),
+        ("nuc_weight_matrix", c_float_p), ("nuc_sq_sigma_matrix", c_float_p),
     ]
 
 
@@ -60,7 +62,7 @@ class RtdOptions(C.Structure):
         ("dose_to_water", C.c_int32), ("nozzle", C.c_int32),
         ("bp_depth_cutoff", C.c_float), ("conv_sigma_cutoff", C.c_float),
         ("ks_sigma_cutoff", C.c_float), ("ray_weight_cutoff", C.c_float),
-        ("fine_grained_timing", C.c_int32), ("reserved", C.c_int32 * 4),
+        ("fine_grained_timing", C.c_int32), ("nuclear_corr", C.c_int32), ("reserved", C.c_int32 * 3),
     ]
 
 
@@ -117,6 +119,7 @@ def default_options():
     o.ks_sigma_cutoff = 3.0
     o.ray_weight_cutoff = 1.0
     o.fine_grained_timing = 0
+    o.nuclear_corr = 0
     return o
 
 

@@ -88,6 +88,13 @@ struct rtd_field_impl {
     LayerPlan* dLayers = nullptr;
     float* dStepTab = nullptr;
     int* dActive = nullptr;      // [L][S][4] minima of (x, y, -x, -y) over rays with dose > 0
+    // NUCLEAR_CORR (default off): the halo on the spot-resolution grid
+    int* dNucSpotIdx = nullptr; float *dNucRayWeights = nullptr, *dNucIdd = nullptr, *dNucRs = nullptr, *dNucBev = nullptr;
+    int* dNucEffT = nullptr;
+    FieldState* dStateNuc = nullptr;
+    FromFan nucIdxToDoseIdx{};
+    TransferParams transfer0Nuc{};
+    int transferModeNuc = 0;
     long long* dFillDbg = nullptr; size_t fillDbgN = 0;   // RTD_FILL_DEBUG: per-block clock stamps of k_fill (diagnostics)
     FieldState* dState = nullptr;
     FieldState* hState = nullptr;      // pinned host mirror of *dState (written by k_ks_plan), and its device-side address
@@ -296,13 +303,19 @@ int rtd_set_luts(rtd_handle hh, const rtd_luts* l) {   // kernel_wrapper.cu:453-
         return fail(h, RTD_ERR_INVALID_ARG, "rtd_set_luts: empty or null table");
     RTD_HIP(h, hipSetDevice(h->device));
     const size_t nC = (size_t)l->n_energies * l->n_energy_samples, nD = l->n_density_samples, nS = l->n_sp_samples, nR = l->n_rrl_samples;
+    const bool nuc = l->nuc_weight_matrix && l->nuc_sq_sigma_matrix;    // NUCLEAR_CORR tables (energy_struct.h:33-36), optional
     if (h->dLutBlock) { RTD_HIP(h, hipStreamSynchronize(h->stream)); RTD_HIP(h, hipFree(h->dLutBlock)); h->dLutBlock = nullptr; }
-    RTD_HIP(h, hipMalloc((void**)&h->dLutBlock, (nC + nD + nS + nR) * sizeof(float)));
+    RTD_HIP(h, hipMalloc((void**)&h->dLutBlock, (nC + nD + nS + nR + (nuc ? 2 * nC : 0)) * sizeof(float)));
     float* p = h->dLutBlock;
     RTD_HIP(h, hipMemcpy(p, l->cidd_matrix, nC * 4, hipMemcpyHostToDevice)); h->lut.cidd = p; p += nC;
     RTD_HIP(h, hipMemcpy(p, l->density_vector, nD * 4, hipMemcpyHostToDevice)); h->lut.density = p; p += nD;
     RTD_HIP(h, hipMemcpy(p, l->sp_vector, nS * 4, hipMemcpyHostToDevice)); h->lut.sp = p; p += nS;
-    RTD_HIP(h, hipMemcpy(p, l->rrl_vector, nR * 4, hipMemcpyHostToDevice)); h->lut.rrl = p;
+    RTD_HIP(h, hipMemcpy(p, l->rrl_vector, nR * 4, hipMemcpyHostToDevice)); h->lut.rrl = p; p += nR;
+    h->lut.nucWeight = nullptr; h->lut.nucSqSigma = nullptr;
+    if (nuc) {
+        RTD_HIP(h, hipMemcpy(p, l->nuc_weight_matrix, nC * 4, hipMemcpyHostToDevice)); h->lut.nucWeight = p; p += nC;
+        RTD_HIP(h, hipMemcpy(p, l->nuc_sq_sigma_matrix, nC * 4, hipMemcpyHostToDevice)); h->lut.nucSqSigma = p;
+    }
     h->lut.nSamples = l->n_energy_samples; h->lut.nEnergies = l->n_energies;
     h->lut.nDensity = (int)nD; h->lut.nSp = (int)nS; h->lut.nRrl = (int)nR;
     h->energiesPerU.assign(l->energies_per_u, l->energies_per_u + l->n_energies);
@@ -348,6 +361,28 @@ int rtd_load_luts_dir(rtd_handle hh, const char* dir, int water_cube_test) {   /
     const char* rname = water_cube_test ? "radiation_length_inc_water.txt" : "radiation_length.txt";
     if (!one(rname, l.n_rrl_samples, l.rrl_scale_fact, rv))
         return fail(h, RTD_ERR_IO, "Failed to open " + d + rname);
+    // NUCLEAR_CORR: the variant's table, checked against the cumulative-IDD table like the reference does (energy_reader.cpp:103-162)
+    std::vector<float> nw, nq;
+    if (h->opt.nuclear_corr != RTD_NUC_OFF) {
+        const char* nname = h->opt.nuclear_corr == RTD_NUC_SOUKUP ? "nuclear_weights_and_sigmas_Soukup.txt"
+                          : h->opt.nuclear_corr == RTD_NUC_FLUKA ? "nuclear_weights_and_sigmas_Fluka.txt" : "nuclear_weights_and_sigmas_fit.txt";
+        std::vector<double> tt;
+        if (!readTokens(d + nname, tt) || tt.size() < 2) return fail(h, RTD_ERR_IO, "Failed to open " + d + nname);
+        if ((int)tt[0] != nS || (int)tt[1] != nE)
+            return fail(h, RTD_ERR_IO, std::string("Number of samples or energies in ") + nname + " different from proton_cumul_ddd_data.txt");
+        if (tt.size() < 2 + 3 * (size_t)nE + 2 * (size_t)nS * nE) return fail(h, RTD_ERR_IO, "Truncated " + d + nname);
+        size_t q = 2;
+        const std::vector<float>* axes[3] = { &e, &p, &s };
+        const char* what[3] = { "Energies", "Peak depths", "Scale facts" };
+        for (int a = 0; a < 3; ++a)
+            for (int i = 0; i < nE; ++i)
+                if (std::fabs((*axes[a])[i] - (float)tt[q++]) > 0.01f)
+                    return fail(h, RTD_ERR_IO, std::string(what[a]) + " in " + nname + " different from proton_cumul_ddd_data.txt");
+        nw.resize((size_t)nS * nE); nq.resize((size_t)nS * nE);
+        for (auto& v : nw) v = (float)tt[q++];
+        for (auto& v : nq) v = (float)tt[q++];
+        l.nuc_weight_matrix = nw.data(); l.nuc_sq_sigma_matrix = nq.data();
+    }
     l.n_energy_samples = nS; l.n_energies = nE;
     l.energies_per_u = e.data(); l.peak_depths = p.data(); l.scale_facts = s.data(); l.cidd_matrix = m.data();
     l.density_vector = dv.data(); l.sp_vector = sv.data(); l.rrl_vector = rv.data();
@@ -385,7 +420,8 @@ int rtd_field_destroy(rtd_handle hh, rtd_field ff) {
     (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = { f->dSpotWeights, f->dConvInterm, f->dRayWeights, f->dDensity, f->dWepl, f->dRrl, f->dIdd, f->dRSigma, f->dBev, f->dBevPart,
                      f->dFirstInside, f->dFirstOutside, f->dFirstPassive, f->dWeplMin, f->dBlockWeplMin, f->dTileRad,
-                     f->dLayers, f->dState, f->dStepTab, f->dActive, f->dFillDbg };
+                     f->dLayers, f->dState, f->dStepTab, f->dActive, f->dFillDbg,
+                     f->dNucSpotIdx, f->dNucRayWeights, f->dNucIdd, f->dNucRs, f->dNucBev, f->dNucEffT, f->dStateNuc };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (f->hState) (void)hipHostFree(f->hState);
     for (auto& e : f->ev) if (e) (void)hipEventDestroy(e);
@@ -399,7 +435,7 @@ int rtd_field_release(rtd_handle hh, rtd_field ff) {
     auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
     auto* f = reinterpret_cast<rtd_field_impl*>(ff);
     if (!h || !f) return RTD_ERR_INVALID_ARG;
-    if (f->remote || h->fieldCache.size() >= 4) return rtd_field_destroy(hh, ff);
+    if (f->remote || f->fc.nuclearCorr || h->fieldCache.size() >= 4) return rtd_field_destroy(hh, ff);
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);      // its kernels have drained: the next owner uploads with plain copies
     f->computed = false; f->transferred = false;
@@ -455,6 +491,14 @@ static int createField(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dim
     fc.bpDepthCutoff = opt.bp_depth_cutoff; fc.convSigmaCutoff = opt.conv_sigma_cutoff;
     fc.ksSigmaCutoff = opt.ks_sigma_cutoff; fc.rayWeightCutoff = opt.ray_weight_cutoff;
     fc.doseToWater = opt.dose_to_water; fc.nozzle = opt.nozzle;
+    fc.nuclearCorr = remote ? 0 : opt.nuclear_corr;
+    fc.nucW = fc.nuclearCorr ? roundTo((int)b->spot_nx, kSuperpTileX) : 0;                                     // :667
+    fc.nucH = fc.nuclearCorr ? roundTo((int)b->spot_ny, kSuperpTileY) : 0;
+    fc.spotDist = sitg.delta.x / b->ray_spacing[0];                                                            // spotDistInRays, :922
+    if (fc.nuclearCorr && (!h->lut.nucWeight || !h->lut.nucSqSigma)) {
+        delete f;
+        return fail(h, RTD_ERR_INVALID_ARG, "nuclear_corr is set but the LUTs carry no nuclear tables");
+    }
     std::memcpy(f->doseDims, dose_dims, sizeof f->doseDims);
     f->R = (size_t)W * H;
 
@@ -553,6 +597,38 @@ static int createField(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dim
         }
         if (e == hipSuccess) e = hipMemcpy(f->dStepTab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice);
     }
+    if (fc.nuclearCorr && e == hipSuccess) {
+        // NUCLEAR_CORR set-up (kernel_wrapper.cu:736-751, 858-892): spot index of every ray, padded spot weights, halo buffers
+        const size_t nucR = (size_t)fc.nucW * fc.nucH, bevN = (size_t)(fc.nucW + 2 * kMaxSuperpR) * (fc.nucH + 2 * kMaxSuperpR);
+        const size_t nTn = (size_t)(fc.nucW / kSuperpTileX) * (fc.nucH / kSuperpTileY);
+        std::vector<int> spotIdx(R, -1);
+        for (unsigned int sy = 0; sy < b->spot_ny; ++sy) {
+            const float gy = (float)sy * sitg.delta.y + sitg.offset.y;
+            const int ry = (int)std::round((gy - off.y) / res.y);
+            for (unsigned int sx = 0; sx < b->spot_nx; ++sx) {
+                const float gx = (float)sx * sitg.delta.x + sitg.offset.x;
+                const int rx = (int)std::round((gx - off.x) / res.x);
+                if (rx >= 0 && rx < W && ry >= 0 && ry < H) spotIdx[(size_t)W * ry + rx] = fc.nucW * (int)sy + (int)sx;
+            }
+        }
+        std::vector<float> padded(nucR * (size_t)L, 0.0f);               // extendAndPadd, :51-66
+        for (int z = 0; z < L; ++z) for (unsigned int y = 0; y < b->spot_ny; ++y) for (unsigned int x = 0; x < b->spot_nx; ++x)
+            padded[(size_t)z * nucR + (size_t)y * fc.nucW + x] = b->spot_weights[((size_t)z * b->spot_ny + y) * b->spot_nx + x];
+        int stn = RTD_OK;
+        auto An = [&](auto** p, size_t n) { if (stn == RTD_OK) stn = devAlloc(h, p, n); };
+        An(&f->dNucSpotIdx, R); An(&f->dNucRayWeights, nucR * L); An(&f->dNucIdd, nucR * L); An(&f->dNucRs, nucR * L);
+        An(&f->dNucBev, bevN); An(&f->dNucEffT, nTn * L); An(&f->dStateNuc, (size_t)1);
+        if (stn != RTD_OK) { rtd_field_destroy(hh, reinterpret_cast<rtd_field>(f)); return stn; }
+        e = hipMemcpy(f->dNucSpotIdx, spotIdx.data(), R * sizeof(int), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(f->dNucRayWeights, padded.data(), padded.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemset(f->dStateNuc, 0, sizeof(FieldState));
+        // the halo cube lives on the spot grid: its own fan transform (:1221) and transfer parameters (:1245, shift by -entry step = 0)
+        f->nucIdxToDoseIdx.fitf = sitg; f->nucIdxToDoseIdx.gtii = toAffine(b->gantry_to_dose_idx);
+        f->nucIdxToDoseIdx.dist.x = b->source_dist[0]; f->nucIdxToDoseIdx.dist.y = b->source_dist[1];
+        f->transfer0Nuc = makeTransferParams(invertAndShift(f->nucIdxToDoseIdx, v3((float)kMaxSuperpR, (float)kMaxSuperpR, 0.0f)));
+        const float ax = std::fabs(f->transfer0Nuc.coefIdxI.x), ay = std::fabs(f->transfer0Nuc.coefIdxJ.x), az = std::fabs(f->transfer0Nuc.inc.x);
+        f->transferModeNuc = std::max(ay, az) > kTransferAxisRatio * ax ? (ay >= az ? 1 : 2) : 0;
+    }
     if (fresh) for (auto& ev : f->ev) if (e == hipSuccess) e = hipEventCreate(&ev);
     if (e != hipSuccess) { h->error = std::string("HIP error: ") + hipGetErrorString(e); rtd_field_destroy(hh, reinterpret_cast<rtd_field>(f)); return RTD_ERR_HIP; }
     // (the transfer reads the slices [entry, passive) only, and the superposition's reduce writes every pixel of those: slices
@@ -607,7 +683,8 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
         RTD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_trace_scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scanLds));
         h->scanLdsSet = true;
     }
-    const ResetJob resetJob{f->dLayers, fc.L, reinterpret_cast<unsigned int*>(f->dTileRad), f->tileRadWords, f->dActive, (size_t)4 * fc.L * fc.S};
+    const ResetJob resetJob{f->dLayers, fc.L, reinterpret_cast<unsigned int*>(f->dTileRad), f->tileRadWords, f->dActive, (size_t)4 * fc.L * fc.S,
+                            f->dNucIdd, f->dNucRs, fc.nuclearCorr ? (size_t)fc.nucW * fc.nucH * fc.L : (size_t)0};
     launchK(k_trace_scan, dim3((unsigned)(f->R / 64)), dim3(64, kScanWaves), scanLds, s, nullptr, ev(1), (const float*)f->dIdd, f->dWepl, fc.W, fc.H,
             (unsigned)fc.S, f->dFirstInside, f->dFirstOutside, f->dState, f->dBlockWeplMin, resetJob);
     k_plan<<<1, 1024, 0, s>>>(f->dState, f->dLayers, (const float*)f->dBlockWeplMin, (int)(f->R / 64), f->dWeplMin, fc);
@@ -618,6 +695,7 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
         const size_t fillLds = (size_t)(2 * h->lut.nSamples) * sizeof(float);   // the layer's two cumulative-IDD rows
         const dim3 fillGrid(2 * rayGrid.x * rayGrid.y * fc.L);          // (layer, tile, role) items: sigma walk and dose walk of every tile; placement is decided in the kernel
         const dim3 fillBlk = blk;
+        const NucFill nucFill{f->dNucSpotIdx, f->dNucRayWeights, f->dNucIdd, f->dNucRs};
         if (!f->dFillDbg && std::getenv("RTD_FILL_DEBUG")) {
             f->fillDbgN = (size_t)4 * fillGrid.x;
             RTD_HIP(h, hipMalloc((void**)&f->dFillDbg, f->fillDbgN * sizeof(long long)));
@@ -625,14 +703,24 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
         if (fillLds <= 40 * 1024)     // + ~17 KiB of static exchange arrays: stays under the 64 KiB default cap of a block's LDS
             launchK((k_fill<true>), fillGrid, fillBlk, fillLds, s, nullptr, ev(3), (const float*)f->dDensity, (const float*)f->dWepl, (const float*)f->dRrl, f->dIdd,
                                   f->dRSigma, (const float*)f->dRayWeights, (const int*)f->dFirstInside, (const int*)f->dFirstOutside,
-                                  f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc, (const float*)f->dStepTab, f->dActive, h->numCUs, f->dFillDbg);
+                                  f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc, (const float*)f->dStepTab, f->dActive, h->numCUs, f->dFillDbg, nucFill);
         else
             launchK((k_fill<false>), fillGrid, fillBlk, 0, s, nullptr, ev(3), (const float*)f->dDensity, (const float*)f->dWepl, (const float*)f->dRrl, f->dIdd,
                                   f->dRSigma, (const float*)f->dRayWeights, (const int*)f->dFirstInside, (const int*)f->dFirstOutside,
-                                  f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc, (const float*)f->dStepTab, f->dActive, h->numCUs, f->dFillDbg);
+                                  f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc, (const float*)f->dStepTab, f->dActive, h->numCUs, f->dFillDbg, nucFill);
+    }
+    if (fc.nuclearCorr) {
+        // the halo's plan runs first: its radius overflow (kernel_wrapper.cu:984) is reported in the primary state, which k_ks_plan mirrors
+        k_nuc_plan<<<1, 256, 0, s>>>(f->dState, f->dStateNuc, (const LayerPlan*)f->dLayers, (const float*)f->dNucRs, f->dNucEffT, fc,
+                                     f->nucIdxToDoseIdx, f->transfer0Nuc, (int)f->doseDims[0], (int)f->doseDims[1], (int)f->doseDims[2]);
     }
     launchK(k_ks_plan, dim3(1), dim3(256), 0, s, nullptr, f->ev[4], f->dState, f->dLayers, fc, f->rayIdxToDoseIdx, f->transfer0,
-                          (int)f->doseDims[0], (int)f->doseDims[1], (int)f->doseDims[2], f->ksGroups, f->dHostState);
+                          (int)f->doseDims[0], (int)f->doseDims[1], (int)f->doseDims[2], f->ksGroups, f->dHostState, f->dStateNuc);
+    if (fc.nuclearCorr) {
+        const int nPix = (fc.nucW + 2 * kMaxSuperpR) * (fc.nucH + 2 * kMaxSuperpR);
+        k_nuc_superpose<<<(nPix + 255) / 256, 256, 0, s>>>((const float*)f->dNucIdd, (const float*)f->dNucRs, (const int*)f->dNucEffT,
+                                                           (const FieldState*)f->dStateNuc, fc, f->dNucBev);
+    }
     {
         const int nTX = (fc.bevW + kKsTileX - 1) / kKsTileX, nTY = (fc.bevH + kKsTileY - 1) / kKsTileY;
         const int G = f->ksGroups;
@@ -679,15 +767,24 @@ int rtd_field_transfer(rtd_handle hh, rtd_field ff, float* dev_dose, const int32
         // grid-stride over the bricks of the device-side box; never more blocks than bricks of the whole volume
         const size_t allBricks = (size_t)((f->doseDims[0] + 31) / 32) * ((f->doseDims[1] + 7) / 8) * ((f->doseDims[2] + zChunk - 1) / zChunk);
         const unsigned tg = (unsigned)std::min<size_t>(allBricks, (size_t)h->numCUs * 8 * 4);
-        auto launchT = [&](auto kern) {
-            launchK(kern, dim3(tg), blk, 0, s, f->remote ? f->ev[0] : nullptr, f->ev[6], dev_dose, (int)f->doseDims[0], (int)f->doseDims[1],
-                    (int)f->doseDims[2], bev, st, fc, zChunk, clip);
+        const bool halo = !f->remote && fc.nuclearCorr != 0;
+        auto launchT = [&](auto kern, const float* slab, const FieldState* state, hipEvent_t startEv, hipEvent_t stopEv) {
+            launchK(kern, dim3(tg), blk, 0, s, startEv, stopEv, dev_dose, (int)f->doseDims[0], (int)f->doseDims[1],
+                    (int)f->doseDims[2], slab, state, fc, zChunk, clip);
         };
         // lanes run along the dose axis that moves fastest along BEV x, so that the gathers stay within few BEV rows
+        hipEvent_t e0 = f->remote ? f->ev[0] : nullptr, e1 = halo ? nullptr : f->ev[6];
         switch (f->transferMode) {
-            case 0: launchT(k_transfer); break;
-            case 1: launchT(k_transfer_t<1>); break;
-            default: launchT(k_transfer_t<2>); break;
+            case 0: launchT(k_transfer, bev, st, e0, e1); break;
+            case 1: launchT(k_transfer_t<1>, bev, st, e0, e1); break;
+            default: launchT(k_transfer_t<2>, bev, st, e0, e1); break;
+        }
+        if (halo) {   // NUCLEAR_CORR: nucTransfDiv (kernel_wrapper.cu:100-127, launch :1221-1254) after the primary transfer, like the reference
+            switch (f->transferModeNuc) {
+                case 0: launchT(k_transfer, (const float*)f->dNucBev, (const FieldState*)f->dStateNuc, nullptr, f->ev[6]); break;
+                case 1: launchT(k_transfer_t<1>, (const float*)f->dNucBev, (const FieldState*)f->dStateNuc, nullptr, f->ev[6]); break;
+                default: launchT(k_transfer_t<2>, (const float*)f->dNucBev, (const FieldState*)f->dStateNuc, nullptr, f->ev[6]); break;
+            }
         }
     }
     RTD_HIP(h, hipGetLastError());
@@ -713,6 +810,9 @@ int rtd_field_clear_dose_box(rtd_handle hh, rtd_field ff, float* dev_dose, const
     const FieldState* st = f->remote ? reinterpret_cast<const FieldState*>(f->attached) : f->dState;
     k_clear_box<<<g, dim3(kSuperpTileX, kSuperpTileY), 0, h->stream>>>(dev_dose, (int)f->doseDims[0], (int)f->doseDims[1], st, zChunk,
                                                                        makeClip(clip_min, clip_max));
+    if (!f->remote && f->fc.nuclearCorr)     // the halo's dose box (its slice reaches further sideways than the primary's)
+        k_clear_box<<<g, dim3(kSuperpTileX, kSuperpTileY), 0, h->stream>>>(dev_dose, (int)f->doseDims[0], (int)f->doseDims[1],
+                                                                           (const FieldState*)f->dStateNuc, zChunk, makeClip(clip_min, clip_max));
     RTD_HIP(h, hipGetLastError());
     return RTD_OK;
 }
@@ -753,6 +853,7 @@ int rtd_field_export_bev(rtd_handle hh, rtd_field ff, void* dev_buf, size_t capa
     auto* f = reinterpret_cast<rtd_field_impl*>(ff);
     if (!h || !f || !dev_buf || capacity < (size_t)kPackHeader) return RTD_ERR_INVALID_ARG;
     if (!f->computed || f->remote) return fail(h, RTD_ERR_NOT_READY, "rtd_field_export_bev: field not computed on this handle");
+    if (f->fc.nuclearCorr) return fail(h, RTD_ERR_INVALID_ARG, "rtd_field_export_bev: the halo slab of nuclear_corr is not exported (one GPU per field only)");
     RTD_HIP(h, hipSetDevice(h->device));
     k_pack_bev<<<dim3((unsigned)h->numCUs * 4), dim3(256), 0, h->stream>>>((const float*)f->dBev, (const FieldState*)f->dState, f->fc,
                                                                            reinterpret_cast<unsigned char*>(dev_buf), capacity);

@@ -28,6 +28,7 @@ struct LutView {
     const float* sp; int nSp;
     const float* rrl; int nRrl;
     const float* cidd; int nSamples; int nEnergies;
+    const float* nucWeight; const float* nucSqSigma;   // NUCLEAR_CORR tables, [nEnergies][nSamples] like cidd (null when absent)
 };
 
 // Per-layer record. Host fills the beam-model part at field creation; k_plan / k_fill / k_ks_plan fill the rest.
@@ -79,6 +80,10 @@ struct FieldConst {
     float maxPeakDepth;             // kernel_wrapper.cu:792-794
     float bpDepthCutoff, convSigmaCutoff, ksSigmaCutoff, rayWeightCutoff;
     int doseToWater, nozzle;
+    // NUCLEAR_CORR (default off; include/rtd.h: RTD_NUC_*): variant, nuclear grid = spot grid rounded up to whole tiles
+    // (kernel_wrapper.cu:667), spot pitch in rays (:922)
+    int nuclearCorr, nucW, nucH;
+    float spotDist;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -192,6 +197,7 @@ struct ResetJob {
     LayerPlan* layers; int L;
     unsigned int* tileRadWords; size_t nRadWords;
     int* active; size_t nActive;
+    float* nucIdd; float* nucRs; size_t nNuc;      // NUCLEAR_CORR: (0, inf) = the reference's fills at kernel_wrapper.cu:862-863
 };
 __device__ inline void resetFieldArrays(const ResetJob& j, size_t t, size_t nT) {
     for (size_t l = t; l < (size_t)j.L; l += nT) {
@@ -200,6 +206,7 @@ __device__ inline void resetFieldArrays(const ResetJob& j, size_t t, size_t nT) 
     }
     for (size_t i = t; i < j.nRadWords; i += nT) j.tileRadWords[i] = 0xFFFFFFFFu;    // every (layer, step, tile): "not classified"
     for (size_t i = t; i < j.nActive; i += nT) j.active[i] = 0x7f7f7f7f;             // empty dose rectangles (+large minima)
+    for (size_t i = t; i < j.nNuc; i += nT) { j.nucIdd[i] = 0.0f; j.nucRs[i] = __int_as_float(0x7f800000); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -484,6 +491,7 @@ __global__ __launch_bounds__(1024) void k_plan(FieldState* st, LayerPlan* layers
         LayerPlan& p = layers[l];
         p.entrySigmaX = sqrtf(p.airCoefA * entryZ * entryZ + p.airCoefB * entryZ + p.spotSigmaX * p.spotSigmaX);
         p.entrySigmaY = sqrtf(p.airCoefA * entryZ * entryZ + p.airCoefB * entryZ + p.spotSigmaY * p.spotSigmaY);
+        if (fc.nuclearCorr == 3) { p.entrySigmaX = 0.97f * p.entrySigmaX; p.entrySigmaY = 0.97f * p.entrySigmaY; }   // GAUSS_FIT, kernel_wrapper.cu:842-847
         unsigned int localAfterLast = (unsigned int)findFirstLargerOrdered(weplMin, fc.S, fc.bpDepthCutoff * p.peakDepth);
         unsigned int g = (unsigned int)sGuaranteed;
         p.afterLast = (int)(localAfterLast < g ? localAfterLast : g);
@@ -583,6 +591,16 @@ __global__ void k_conv_y(const float* __restrict__ in, float* __restrict__ out, 
 
 constexpr int kFillBatch = 8;   // steps per batch: inputs fetched one batch ahead, one block barrier per batch
 
+// NUCLEAR_CORR arguments of the fill (kernel_wrapper.cu:190-198). The reference constructs its fill parameters with a nuclear
+// memory step of 0 (:925), so every step of a ray overwrites the same voxel of the nuclear arrays (:367-373) and what remains
+// after a layer's launch is the value of the LAST step, in plane 0. The engine keeps exactly that: one plane per layer, written
+// once after the walk.
+struct NucFill {
+    const int* spotIdx;            // [H][W] the ray's spot on the nuclear grid, -1 if none (kernel_wrapper.cu:878-892)
+    const float* rayWeights;       // [L][nucH][nucW] padded spot weights (extendAndPadd, :51-66)
+    float* idd; float* rs;         // [L][nucH][nucW] plane 0 of the reference's nuclear arrays after layer l
+};
+
 template <bool LDS_LUT>
 __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensity, const float* __restrict__ bevCumulSp,
                                                const float* __restrict__ bevRrl,
@@ -591,7 +609,7 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
                                                const int* __restrict__ firstOutside, int* __restrict__ firstPassive,
                                                unsigned char* __restrict__ tileRad, LayerPlan* layers, FieldState* st,
                                                LutView lut, FillGeom fg, FieldConst fc, const float* __restrict__ stepTab,
-                                               int* __restrict__ active, int nCU, long long* __restrict__ dbg) {
+                                               int* __restrict__ active, int nCU, long long* __restrict__ dbg, NucFill nuc) {
     extern __shared__ float sLutF[];                                 // dose walk: the layer's two cumulative-IDD rows
     // diagnostic build only (RTD_FILL_DEBUG): per block start / end clock, hardware id, item — no output value depends on it
     const long long dbgT0 = dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
@@ -641,12 +659,18 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
     if (rayWeight < fc.rayWeightCutoff || afterLast < pFirst) { beamLive = false; afterLast = 0; }
     const float cutDepth = lp.peakDepth * fc.bpDepthCutoff;
     float cumulSpOld = 0.0f;
-    const float sqrt2 = 1.41421356f, sigmaDelta = 0.21f;
+    const float sqrt2 = 1.41421356f;
 
     if (role == 0) {
         // ================================ sigma walk ================================
         if (tid < kMaxSuperpR + 2) sHist[tid] = 0;
-        const float pInv = 0.5649718f, eCoef = 8.639415f, eRefSq = 198.81f;
+        const float pInv = 0.5649718f, eCoef = 8.639415f;
+        // E_s^2 and the empirical widening per NUCLEAR_CORR variant (kernel_wrapper.cu:228-245)
+        const float eRefSq = fc.nuclearCorr == 1 ? 190.44f : fc.nuclearCorr == 2 ? 216.09f : fc.nuclearCorr == 3 ? 169.00f : 198.81f;
+        const float sigmaDeltaV = fc.nuclearCorr == 1 ? 0.0f : fc.nuclearCorr == 2 ? 0.08f : fc.nuclearCorr == 3 ? 0.06f : 0.21f;
+        const int nucIdx = fc.nuclearCorr ? nuc.spotIdx[rayIdx] : -1;
+        const float entrySigmaSq = lp.entrySigmaX * lp.entrySigmaX;  // FillIddAndSigmaParams::getEntrySigmaSq (:925, 4th argument)
+        float nucRSigmaEff = __int_as_float(0x7f800000);
         float rSigmaEff = 0.0f, incScat = 0.0f, incincScat = 0.0f;
         float incDiv = lp.sigmaSqAirLin + (2.0f * (float)pFirst - 1.0f) * lp.sigmaSqAirQuad;
         float sigmaSq = -incDiv;
@@ -682,17 +706,23 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
                         incScat += incincScat;
                         incDiv += 2.0f * lp.sigmaSqAirQuad;
                     } else {
-                        sigmaSq -= 1.5f * (incScat + incDiv) * density;
+                        if (fc.nuclearCorr != 3) sigmaSq -= 1.5f * (incScat + incDiv) * density;   // (not for GAUSS_FIT, :300-302)
                     }
                     // stepTab[2k] = 0.5*(voxelWidth(k).x + voxelWidth(k).y): per-step constant evaluated once on the host with the
                     // reference's expressions (fill_idd_and_sigma_params.cu:42-46). Hardware sqrt / reciprocal: this value only
                     // weights the superposition; the radius class comes from sigmaSq itself (below).
-                    rSigmaEff = stepTab[2 * stepNo] * __builtin_amdgcn_rcpf(sqrt2 * (__builtin_amdgcn_sqrtf(sigmaSq) + sigmaDelta));
+                    rSigmaEff = stepTab[2 * stepNo] * __builtin_amdgcn_rcpf(sqrt2 * (__builtin_amdgcn_sqrtf(sigmaSq) + sigmaDeltaV));
+                    if (nucIdx >= 0) {                               // :332-341 (IEEE: its tile minimum becomes a radius class too)
+                        const float nucSqSigma = sample2dClamp(lut.nucSqSigma, lut.nSamples, lut.nEnergies,
+                                                               0.5f * (cumulSp + cumulSpOld) * lp.energyScaleFact, lp.energyIdx);
+                        const Vec2 vw = fg.voxelWidth(stepNo);
+                        nucRSigmaEff = 0.5f * fc.spotDist * (vw.x + vw.y) / (sqrt2 * sqrtf(sigmaSq + nucSqSigma + entrySigmaSq));
+                    }
                     if (cumulSp > cutDepth || stepNo == afterLast) { beamLive = false; afterLast = stepNo; }
                     cumulSpOld = cumulSp;
                 }
                 float sig = sigmaSq;
-                if (!beamLive || (int)stepNo < (firstIn - 1)) { rSigmaEff = __int_as_float(0x7f800000); sig = -1.0f; }
+                if (!beamLive || (int)stepNo < (firstIn - 1)) { rSigmaEff = __int_as_float(0x7f800000); sig = -1.0f; nucRSigmaEff = __int_as_float(0x7f800000); }
                 (bevRSigmaEff + layerOff + (size_t)stepNo * memStep)[rayOff] = rSigmaEff;
                 sSig[buf][j][tid] = sig;
             }
@@ -706,7 +736,7 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
                 if (l == 31 && step0 + j < pAfterLast) {
                     // tile minimum of 1/sigma (= the reference's minVal, kernel_wrapper.cuh:282-297) from the tile maximum of
                     // sigmaSq with IEEE sqrt and division, then the class exactly as the reference computes it (:300-305)
-                    const float minRs = m >= 0.0f ? stepTab[2 * (step0 + j)] / (sqrt2 * (sqrtf(m) + sigmaDelta)) : __int_as_float(0x7f800000);
+                    const float minRs = m >= 0.0f ? stepTab[2 * (step0 + j)] / (sqrt2 * (sqrtf(m) + sigmaDeltaV)) : __int_as_float(0x7f800000);
                     int rad = f2iSat(fc.ksSigmaCutoff / (sqrtf(2.0f) * minRs) + 0.5f);
                     rad = rad > kMaxSuperpR + 1 ? kMaxSuperpR + 1 : rad;
                     rad = rad < 0 ? 0 : rad;
@@ -716,6 +746,7 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
             }
         }
         firstPassive[(size_t)layer * memStep + rayIdx] = (int)afterLast;
+        if (nucIdx >= 0 && pFirst < pAfterLast) nuc.rs[(size_t)layer * fc.nucW * fc.nucH + nucIdx] = nucRSigmaEff;   // value of the last step (:367-373)
         int mx = waveMaxI((int)afterLast);
         if ((tid & (kWave - 1)) == 0) atomicMax(&layers[layer].layerFirstPassive, mx);
         __syncthreads();
@@ -737,6 +768,9 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
         float* sRow1 = sLutF + lut.nSamples;
         if (LDS_LUT) for (int i = tid; i < lut.nSamples; i += 256) { sRow0[i] = gRow0[i]; sRow1[i] = gRow1[i]; }
         float res = 0.0f, cumulDoseOld = 0.0f;
+        const int nucIdx = fc.nuclearCorr ? nuc.spotIdx[rayIdx] : -1;
+        const float nucRayWeight = nucIdx >= 0 ? nuc.rayWeights[(size_t)layer * fc.nucW * fc.nucH + nucIdx] : 0.0f;
+        float nucRes = 0.0f;
         int actUni = 0x7fffffff;
         float spB[kFillBatch], denB[kFillBatch];
         auto fetch1 = [&](int j, unsigned int stepNo) {
@@ -776,11 +810,18 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
                     const float stepVol = stepTab[2 * stepNo + 1];
                     const float mass = fc.doseToWater ? (cumulSp - cumulSpOld) * stepVol : density * stepVol;
                     // (the dose value feeds no threshold other than res > 0, which a reciprocal cannot change: hardware reciprocal, <= 1 ulp)
-                    if (mass > 1e-2f) res = rayWeight * (cumulDose - cumulDoseOld) * __builtin_amdgcn_rcpf(mass);
+                    if (!fc.nuclearCorr) {
+                        if (mass > 1e-2f) res = rayWeight * (cumulDose - cumulDoseOld) * __builtin_amdgcn_rcpf(mass);
+                    } else if (mass > 1e-2f) {                       // :320-331: the primary keeps (1 - nucWeight), the halo gets nucWeight
+                        const float nucWeight = sample2dClamp(lut.nucWeight, lut.nSamples, lut.nEnergies,
+                                                              0.5f * (cumulSp + cumulSpOld) * lp.energyScaleFact, lp.energyIdx);
+                        res = (1.0f - nucWeight) * rayWeight * (cumulDose - cumulDoseOld) * __builtin_amdgcn_rcpf(mass);
+                        nucRes = nucWeight * nucRayWeight * (cumulDose - cumulDoseOld) / (mass * fc.spotDist * fc.spotDist);
+                    }
                     cumulSpOld = cumulSp;
                     cumulDoseOld = cumulDose;
                 }
-                if (!beamLive || (int)stepNo < (firstIn - 1)) res = 0.0f;
+                if (!beamLive || (int)stepNo < (firstIn - 1)) { res = 0.0f; nucRes = 0.0f; }
                 (bevIdd + layerOff + (size_t)stepNo * memStep)[rayOff] = res;
                 doseMask[j] = __ballot(res > 0.0f);
             }
@@ -811,6 +852,7 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
             }
         }
         if ((tid & 31) < 4 && actUni != 0x7fffffff) atomicMin(&st->actUnion[tid & 3], actUni);
+        if (nucIdx >= 0 && pFirst < pAfterLast) nuc.idd[(size_t)layer * fc.nucW * fc.nucH + nucIdx] = nucRes;   // value of the last step (:367-373)
     }
     if (dbg && tid == 0) {
         long long* q = dbg + 4 * (size_t)blockIdx.x;
@@ -821,11 +863,61 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
     }
 }
 
+// The two boxes of a transfer (kernel_wrapper.cu:1185-1213): bbox = the reference's minIdx / maxIdx from the eight corners of the
+// padded BEV cube (W x H rays, slices [first, calcPassive)); tbox = the voxels the transfer can actually change: the image of
+// the block of the slab that can be non-zero — pixels [bevLo, bevHi], slices [slabLo, slabHi) — grown by the interpolation reach,
+// clipped by the voxels the reference's launch visits.
+__device__ inline void transferBoxes(const FromFan& rayIdxToDoseIdx, int W, int H, int first, int calcPassive, const int bevLo[2], const int bevHi[2],
+                                     int slabLo, int slabHi, int doseNx, int doseNy, int doseNz, int bboxMin[3], int bboxMax[3], int tboxMin[3], int tboxMax[3]) {
+    Vec3 maxP = v3(-1.0f, -1.0f, -1.0f), minP = v3(100000.0f, 100000.0f, 100000.0f);
+    float xVals[2] = { -(float)kMaxSuperpR, (float)(W + kMaxSuperpR - 1) };
+    float yVals[2] = { -(float)kMaxSuperpR, (float)(H + kMaxSuperpR - 1) };
+    float zVals[2] = { (float)first, (float)(calcPassive - 1) };
+    for (int zi = 0; zi < 2; ++zi) for (int yi = 0; yi < 2; ++yi) for (int xi = 0; xi < 2; ++xi) {
+        Vec3 p = transformPoint(rayIdxToDoseIdx, v3(xVals[xi], yVals[yi], zVals[zi]));
+        if (p.x > maxP.x) maxP.x = p.x; if (p.y > maxP.y) maxP.y = p.y; if (p.z > maxP.z) maxP.z = p.z;
+        if (p.x < minP.x) minP.x = p.x; if (p.y < minP.y) minP.y = p.y; if (p.z < minP.z) minP.z = p.z;
+    }
+    int t;
+    t = (((int)floorf(minP.x)) / 32) * 32; bboxMin[0] = t > 0 ? t : 0;
+    t = (int)floorf(minP.y); bboxMin[1] = t > 0 ? t : 0;
+    t = (int)floorf(minP.z); bboxMin[2] = t > 0 ? t : 0;
+    t = (int)ceilf(maxP.x); bboxMax[0] = t < doseNx - 1 ? t : doseNx - 1;
+    t = (int)ceilf(maxP.y); bboxMax[1] = t < doseNy - 1 ? t : doseNy - 1;
+    t = (int)ceilf(maxP.z); bboxMax[2] = t < doseNz - 1 ? t : doseNz - 1;
+    // The voxels primTransfDiv visits (kernel_wrapper.cu:69-97, launch :1209-1214): its grid starts at minIdx and is rounded up
+    // to whole 32 x 8 blocks, clipped by the dose dimensions only — x and y run PAST maxIdx up to the block edge — while z
+    // stops at maxIdx.z. Voxels between maxIdx and the block edge do receive dose when the interpolated BEV value there
+    // is non-zero (one BEV step beyond the last slice still interpolates against it), so the coverage is kept exactly.
+    const int covMax[3] = { min(bboxMin[0] + roundToI(bboxMax[0] - bboxMin[0] + 1, 32) - 1, doseNx - 1),
+                            min(bboxMin[1] + roundToI(bboxMax[1] - bboxMin[1] + 1, 8) - 1, doseNy - 1), bboxMax[2] };
+    // the BEV dose is exactly zero outside the padded rectangle [bevLo, bevHi] and outside the slices [slabLo, slabHi):
+    // the image of that block, grown by the interpolation reach (one pixel / one step on every side), bounds the voxels
+    // the transfer can change
+    float txVals[2] = { (float)(bevLo[0] - 32 - 1), (float)(bevHi[0] - 32 + 1) };
+    float tyVals[2] = { (float)(bevLo[1] - 32 - 1), (float)(bevHi[1] - 32 + 1) };
+    float tzVals[2] = { (float)(slabLo - 1), (float)slabHi };
+    maxP = v3(-1.0f, -1.0f, -1.0f); minP = v3(100000.0f, 100000.0f, 100000.0f);
+    for (int zi = 0; zi < 2; ++zi) for (int yi = 0; yi < 2; ++yi) for (int xi = 0; xi < 2; ++xi) {
+        Vec3 p = transformPoint(rayIdxToDoseIdx, v3(txVals[xi], tyVals[yi], tzVals[zi]));
+        if (p.x > maxP.x) maxP.x = p.x; if (p.y > maxP.y) maxP.y = p.y; if (p.z > maxP.z) maxP.z = p.z;
+        if (p.x < minP.x) minP.x = p.x; if (p.y < minP.y) minP.y = p.y; if (p.z < minP.z) minP.z = p.z;
+    }
+    const int lo[3] = { (((int)floorf(minP.x) - 1) / 32) * 32,   // (aligned like the reference's box, :1207)
+                        (int)floorf(minP.y) - 1, (int)floorf(minP.z) - 1 };
+    const int hi[3] = { (int)ceilf(maxP.x) + 1, (int)ceilf(maxP.y) + 1, (int)ceilf(maxP.z) + 1 };
+    for (int i = 0; i < 3; ++i) {
+        tboxMin[i] = lo[i] > bboxMin[i] ? lo[i] : bboxMin[i];
+        tboxMax[i] = hi[i] < covMax[i] ? hi[i] : covMax[i];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K6: superposition plan = host batching of radii (kernel_wrapper.cu:965-976) + beamFirstCalculatedPassive
 // (:955-957) + transfer bounding box and shift (:1185-1213), all on the device.
 __global__ __launch_bounds__(256) void k_ks_plan(FieldState* stGlobal, LayerPlan* layers, FieldConst fc, FromFan rayIdxToDoseIdx, TransferParams tp0,
-                                                 int doseNx, int doseNy, int doseNz, int G, FieldState* __restrict__ hostMirror) {
+                                                 int doseNx, int doseNy, int doseNz, int G, FieldState* __restrict__ hostMirror,
+                                                 FieldState* __restrict__ stNuc) {
     // The state record is completed in LDS and then written out — to device memory and to its pinned host mirror — by all threads,
     // one dword each per trip: this one-block launch sits on the field's critical path, and both a load of the record behind a
     // store to it and a serial copy over PCIe by one thread cost microseconds each.
@@ -907,49 +999,9 @@ __global__ __launch_bounds__(256) void k_ks_plan(FieldState* stGlobal, LayerPlan
         TransferParams tp = tp0;
         tp.globalOffset.z = tp0.globalOffset.z + (-(float)first);   // invertAndShift(..., -beamFirstInside) :1213
         int bboxMin[3] = {0, 0, 0}, bboxMax[3] = {0, 0, 0}, tboxMin[3] = {0, 0, 0}, tboxMax[3] = {-1, -1, -1};
-        if (calcPassive > first) {
-            Vec3 maxP = v3(-1.0f, -1.0f, -1.0f), minP = v3(100000.0f, 100000.0f, 100000.0f);
-            float xVals[2] = { -(float)kMaxSuperpR, (float)(fc.W + kMaxSuperpR - 1) };
-            float yVals[2] = { -(float)kMaxSuperpR, (float)(fc.H + kMaxSuperpR - 1) };
-            float zVals[2] = { (float)first, (float)(calcPassive - 1) };
-            for (int zi = 0; zi < 2; ++zi) for (int yi = 0; yi < 2; ++yi) for (int xi = 0; xi < 2; ++xi) {
-                Vec3 p = transformPoint(rayIdxToDoseIdx, v3(xVals[xi], yVals[yi], zVals[zi]));
-                if (p.x > maxP.x) maxP.x = p.x; if (p.y > maxP.y) maxP.y = p.y; if (p.z > maxP.z) maxP.z = p.z;
-                if (p.x < minP.x) minP.x = p.x; if (p.y < minP.y) minP.y = p.y; if (p.z < minP.z) minP.z = p.z;
-            }
-            int t;
-            t = (((int)floorf(minP.x)) / 32) * 32; bboxMin[0] = t > 0 ? t : 0;
-            t = (int)floorf(minP.y); bboxMin[1] = t > 0 ? t : 0;
-            t = (int)floorf(minP.z); bboxMin[2] = t > 0 ? t : 0;
-            t = (int)ceilf(maxP.x); bboxMax[0] = t < doseNx - 1 ? t : doseNx - 1;
-            t = (int)ceilf(maxP.y); bboxMax[1] = t < doseNy - 1 ? t : doseNy - 1;
-            t = (int)ceilf(maxP.z); bboxMax[2] = t < doseNz - 1 ? t : doseNz - 1;
-            // The voxels primTransfDiv visits (kernel_wrapper.cu:69-97, launch :1209-1214): its grid starts at minIdx and is rounded up
-            // to whole 32 x 8 blocks, clipped by the dose dimensions only — x and y run PAST maxIdx up to the block edge — while z
-            // stops at maxIdx.z. Voxels between maxIdx and the block edge do receive dose when the interpolated BEV value there
-            // is non-zero (one BEV step beyond the last slice still interpolates against it), so the coverage is kept exactly.
-            const int covMax[3] = { min(bboxMin[0] + roundToI(bboxMax[0] - bboxMin[0] + 1, 32) - 1, doseNx - 1),
-                                    min(bboxMin[1] + roundToI(bboxMax[1] - bboxMin[1] + 1, 8) - 1, doseNy - 1), bboxMax[2] };
-            // the BEV dose is exactly zero outside the padded rectangle [bevLo, bevHi] and outside the slices [first, calcPassive):
-            // the image of that block, grown by the interpolation reach (one pixel / one step on every side), bounds the voxels
-            // the transfer can change
-            float txVals[2] = { (float)(bevLo[0] - 32 - 1), (float)(bevHi[0] - 32 + 1) };
-            float tyVals[2] = { (float)(bevLo[1] - 32 - 1), (float)(bevHi[1] - 32 + 1) };
-            float tzVals[2] = { (float)(first - 1), (float)calcPassive };
-            maxP = v3(-1.0f, -1.0f, -1.0f); minP = v3(100000.0f, 100000.0f, 100000.0f);
-            for (int zi = 0; zi < 2; ++zi) for (int yi = 0; yi < 2; ++yi) for (int xi = 0; xi < 2; ++xi) {
-                Vec3 p = transformPoint(rayIdxToDoseIdx, v3(txVals[xi], tyVals[yi], tzVals[zi]));
-                if (p.x > maxP.x) maxP.x = p.x; if (p.y > maxP.y) maxP.y = p.y; if (p.z > maxP.z) maxP.z = p.z;
-                if (p.x < minP.x) minP.x = p.x; if (p.y < minP.y) minP.y = p.y; if (p.z < minP.z) minP.z = p.z;
-            }
-            const int lo[3] = { (((int)floorf(minP.x) - 1) / 32) * 32,   // (aligned like the reference's box, :1207)
-                                (int)floorf(minP.y) - 1, (int)floorf(minP.z) - 1 };
-            const int hi[3] = { (int)ceilf(maxP.x) + 1, (int)ceilf(maxP.y) + 1, (int)ceilf(maxP.z) + 1 };
-            for (int i = 0; i < 3; ++i) {
-                tboxMin[i] = lo[i] > bboxMin[i] ? lo[i] : bboxMin[i];
-                tboxMax[i] = hi[i] < covMax[i] ? hi[i] : covMax[i];
-            }
-        }
+        if (calcPassive > first)
+            transferBoxes(rayIdxToDoseIdx, fc.W, fc.H, first, calcPassive, bevLo, bevHi, first, calcPassive, doseNx, doseNy, doseNz,
+                          bboxMin, bboxMax, tboxMin, tboxMax);
         st->firstCalculatedPassive = calcPassive;
         st->maxRadius = sMaxRad;
         for (int gI = 0; gI < 32; ++gI) st->groupPassive[gI] = sGroup[gI];
@@ -972,9 +1024,102 @@ __global__ __launch_bounds__(256) void k_ks_plan(FieldState* stGlobal, LayerPlan
             dst[i] = v;
             if (hostMirror) mir[i] = v;
         }
+        // NUCLEAR_CORR: a radius overflow of the primary field stops the halo's transfer as well
+        if (stNuc && threadIdx.x == 0 && sSt.errorFlags) stNuc->errorFlags = sSt.errorFlags;
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// NUCLEAR_CORR halo (default off): what the reference's nuclear launches do given its fill (see NucFill).
+// Per layer the reference classifies the tiles of the nuclear arrays for the steps [entry, layerFirstPassive)
+// (kernel_wrapper.cu:978-997) and superposes them (:1058-1091); only plane 0 of those arrays ever holds anything but the
+// initial (0, inf), so the halo cube receives dose in slice 0 only, and only when the beam's entry step is 0.
+// k_nuc_plan   one block: radius class of every (layer, tile) of plane 0, the batching rule per layer, the state record of the
+//              one-slice halo slab (boxes, transfer parameters). A radius overflow is reported in the PRIMARY state (it runs
+//              before k_ks_plan), like the reference's throw at :984.
+// k_nuc_superpose   one thread per pixel of the padded halo slice: the same patches as kernelSuperposition (:432-489), gathered.
+__global__ __launch_bounds__(256) void k_nuc_plan(FieldState* stPrim, FieldState* stNuc, const LayerPlan* __restrict__ layers,
+                                                  const float* __restrict__ nucRs, int* __restrict__ nucEffT, FieldConst fc,
+                                                  FromFan nucIdxToDoseIdx, TransferParams tp0, int doseNx, int doseNy, int doseNz) {
+    __shared__ int sAny, sCalc;
+    if (threadIdx.x == 0) { sAny = 0; sCalc = 0; }
+    __syncthreads();
+    const int first = stPrim->beamFirstInside;
+    const int tX = fc.nucW / kSuperpTileX, tY = fc.nucH / kSuperpTileY, nT = tX * tY;
+    const size_t nucR = (size_t)fc.nucW * fc.nucH;
+    for (int l = threadIdx.x; l < fc.L; l += blockDim.x) {
+        const int lfp = layers[l].layerFirstPassive;
+        atomicMax(&sCalc, lfp);
+        for (int t = 0; t < nT; ++t) nucEffT[l * nT + t] = -1;
+        if (first != 0 || lfp <= 0) continue;                        // plane 0 is not among the steps [first, layerFirstPassive)
+        int hist[kMaxSuperpR + 2];
+        for (int i = 0; i < kMaxSuperpR + 2; ++i) hist[i] = 0;
+        for (int t = 0; t < nT; ++t) {                               // tileRadCalc (kernel_wrapper.cuh:256-313) on plane 0
+            const float* base = nucRs + (size_t)l * nucR + (size_t)(t / tX) * kSuperpTileY * fc.nucW + (t % tX) * kSuperpTileX;
+            float m = base[0];
+            for (int r = 0; r < kSuperpTileY; ++r) for (int c = 0; c < kSuperpTileX; ++c) { const float v = base[r * fc.nucW + c]; m = v < m ? v : m; }
+            int rad = f2iSat(fc.ksSigmaCutoff / (sqrtf(2.0f) * m) + 0.5f);
+            rad = rad > kMaxSuperpR + 1 ? kMaxSuperpR + 1 : (rad < 0 ? 0 : rad);
+            hist[rad] += 1;
+            nucEffT[l * nT + t] = rad;
+        }
+        if (hist[kMaxSuperpR + 1] > 0) { atomicOr(&stPrim->errorFlags, kErrRadiusOverflow); continue; }   // :984
+        int layerMax = 0, eff[kMaxSuperpR + 2];
+        for (int i = 0; i < kMaxSuperpR + 2; ++i) { if (hist[i] > 0) layerMax = i; eff[i] = i; }
+        int rec = layerMax, batched = 0;                             // batching rule, :986-996
+        for (int rad = layerMax; rad > 0; --rad) {
+            batched += hist[rad];
+            eff[rad] = rec;
+            if (batched >= kMinTilesInBatch) { rec = rad - 1; batched = 0; }
+        }
+        for (int t = 0; t < nT; ++t) nucEffT[l * nT + t] = eff[nucEffT[l * nT + t]];
+        atomicOr(&sAny, 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        FieldState s;
+        for (unsigned int i = 0; i < sizeof(FieldState) / 4; ++i) reinterpret_cast<unsigned int*>(&s)[i] = 0u;
+        const int bevW = fc.nucW + 2 * kMaxSuperpR, bevH = fc.nucH + 2 * kMaxSuperpR;
+        s.beamFirstInside = 0;
+        s.firstCalculatedPassive = sAny ? 1 : 0;                     // the one slice that can hold dose
+        s.bevLo[0] = 0; s.bevLo[1] = 0; s.bevHi[0] = bevW - 1; s.bevHi[1] = bevH - 1;
+        s.packX0 = 0; s.packY0 = 0; s.packW = bevW; s.packH = bevH; s.slabFirst = 0;
+        s.transfer = tp0;                                            // (shift by -beamFirstInside = 0, :1245)
+        for (int i = 0; i < 3; ++i) { s.tboxMin[i] = 0; s.tboxMax[i] = -1; }
+        if (sAny) transferBoxes(nucIdxToDoseIdx, fc.nucW, fc.nucH, 0, sCalc, s.bevLo, s.bevHi, 0, 1, doseNx, doseNy, doseNz,
+                                s.bboxMin, s.bboxMax, s.tboxMin, s.tboxMax);
+        *stNuc = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_nuc_superpose(const float* __restrict__ nucIdd, const float* __restrict__ nucRs, const int* __restrict__ nucEffT,
+                                                       const FieldState* __restrict__ stNuc, FieldConst fc, float* __restrict__ bevNuc) {
+    const int bevW = fc.nucW + 2 * kMaxSuperpR, bevH = fc.nucH + 2 * kMaxSuperpR;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= bevW * bevH) return;
+    float acc = 0.0f;
+    if (stNuc->firstCalculatedPassive > 0 && !stNuc->errorFlags) {
+        const int px = pix % bevW, py = pix / bevW;
+        const int tX = fc.nucW / kSuperpTileX, nT = tX * (fc.nucH / kSuperpTileY);
+        const size_t nucR = (size_t)fc.nucW * fc.nucH;
+        for (int l = 0; l < fc.L; ++l)
+            for (int sy = max(py - 32 - kMaxSuperpR, 0); sy <= min(py - 32 + kMaxSuperpR, fc.nucH - 1); ++sy)
+                for (int sx = max(px - 32 - kMaxSuperpR, 0); sx <= min(px - 32 + kMaxSuperpR, fc.nucW - 1); ++sx) {
+                    const int rho = nucEffT[l * nT + (sy / kSuperpTileY) * tX + sx / kSuperpTileX];
+                    const int dx = abs(px - 32 - sx), dy = abs(py - 32 - sy);
+                    if (rho < 0 || dx > rho || dy > rho) continue;
+                    const float dose = nucIdd[(size_t)l * nucR + (size_t)sy * fc.nucW + sx];
+                    if (!(dose > 0.0f)) continue;
+                    const float rs = nucRs[(size_t)l * nucR + (size_t)sy * fc.nucW + sx];
+                    // erfDiffs (kernel_wrapper.cuh:459-467)
+                    const float ex = 0.5f * (erff(rs * ((float)dx + 0.5f)) - erff(rs * ((float)dx - 0.5f)));
+                    const float ey = 0.5f * (erff(rs * ((float)dy + 0.5f)) - erff(rs * ((float)dy - 0.5f)));
+                    acc += dose * ey * ex;
+                }
+    }
+    bevNuc[pix] = acc;
+}
 
 // ------------------------------------------------------------------------------------------------
 // K7: output-stationary kernel superposition on the matrix cores, one autonomous WAVE per work item.

@@ -27,7 +27,7 @@ class EnergyStruct:
     """Host mirror of the reference's EnergyStruct (energy_struct.h:13-31), arrays as float32 numpy."""
 
     def __init__(self, energiesPerU, peakDepths, scaleFacts, ciddMatrix, densityScaleFact, densityVector,
-                 spScaleFact, spVector, rRlScaleFact, rRlVector):
+                 spScaleFact, spVector, rRlScaleFact, rRlVector, nucWeightMatrix=None, nucSqSigmaMatrix=None):
         self.energiesPerU = abi.f32(energiesPerU)
         self.peakDepths = abi.f32(peakDepths)
         self.scaleFacts = abi.f32(scaleFacts)
@@ -43,6 +43,9 @@ class EnergyStruct:
         self.rRlScaleFact = float(np.float32(rRlScaleFact))
         self.rRlVector = abi.f32(rRlVector)
         self.nRRlSamples = int(self.rRlVector.size)
+        # NUCLEAR_CORR tables (energy_struct.h:33-36), same shape as the cumulative IDD matrix; None when not loaded
+        self.nucWeightMatrix = None if nucWeightMatrix is None else abi.f32(nucWeightMatrix).reshape(self.nEnergies, -1)
+        self.nucSqSigmaMatrix = None if nucSqSigmaMatrix is None else abi.f32(nucSqSigmaMatrix).reshape(self.nEnergies, -1)
 
     def as_abi(self):
         """rtd_luts view of the arrays (keeps self alive while in use)."""
@@ -62,6 +65,9 @@ class EnergyStruct:
         s.n_rrl_samples = self.nRRlSamples
         s.rrl_scale_fact = self.rRlScaleFact
         s.rrl_vector = abi.fptr(self.rRlVector)
+        if self.nucWeightMatrix is not None:
+            s.nuc_weight_matrix = abi.fptr(self.nucWeightMatrix)
+            s.nuc_sq_sigma_matrix = abi.fptr(self.nucSqSigmaMatrix)
         return s
 
 
@@ -70,8 +76,12 @@ def _read_tokens(path):
         return fh.read().split()
 
 
-def read_lut_dir(directory, water_cube_test=False):
-    """energyReader(dataPath) (energy_reader.cpp:12-101). water_cube_test selects the *_inc_water file (:77-93)."""
+NUC_FILES = {1: "nuclear_weights_and_sigmas_Soukup.txt", 2: "nuclear_weights_and_sigmas_Fluka.txt", 3: "nuclear_weights_and_sigmas_fit.txt"}
+
+
+def read_lut_dir(directory, water_cube_test=False, nuclear_corr=0):
+    """energyReader(dataPath) (energy_reader.cpp:12-101). water_cube_test selects the *_inc_water file (:77-93); nuclear_corr
+    (abi.RTD_NUC_*) also reads the variant's nuclear table and checks its axes against the IDD table (:103-162)."""
     d = directory if directory.endswith("/") else directory + "/"
     t = _read_tokens(d + FILES["cidd"])
     nS, nE = int(t[0]), int(t[1])
@@ -86,7 +96,18 @@ def read_lut_dir(directory, water_cube_test=False):
     ds, dv = one(FILES["density"])
     ss, sv = one(FILES["sp"])
     rs, rv = one(FILES["rrl_water"] if water_cube_test else FILES["rrl"])
-    return EnergyStruct(e, p, s, m.reshape(nE, nS), ds, dv, ss, sv, rs, rv)
+    nw = nq = None
+    if nuclear_corr:
+        name = NUC_FILES[int(nuclear_corr)]
+        tt = _read_tokens(d + name)
+        if int(tt[0]) != nS or int(tt[1]) != nE:
+            raise RuntimeError("Number of samples or energies in %s different from proton_cumul_ddd_data.txt" % name)
+        w = np.array(tt[2:2 + 3 * nE + 2 * nS * nE], dtype=np.float32)
+        for k, (ref, what) in enumerate(((e, "Energies"), (p, "Peak depths"), (s, "Scale facts"))):
+            if (np.abs(ref - w[k * nE:(k + 1) * nE]) > 0.01).any():
+                raise RuntimeError("%s in %s different from proton_cumul_ddd_data.txt" % (what, name))
+        nw, nq = w[3 * nE:3 * nE + nS * nE].reshape(nE, nS), w[3 * nE + nS * nE:].reshape(nE, nS)
+    return EnergyStruct(e, p, s, m.reshape(nE, nS), ds, dv, ss, sv, rs, rv, nw, nq)
 
 
 def write_lut_dir(directory, es, also_water=True):
@@ -113,6 +134,16 @@ def write_lut_dir(directory, es, also_water=True):
     one(FILES["rrl"], es.rRlScaleFact, es.rRlVector)
     if also_water:
         one(FILES["rrl_water"], es.rRlScaleFact, es.rRlVector)
+    if es.nucWeightMatrix is not None:
+        for name in NUC_FILES.values():
+            with open(d + name, "w") as fh:
+                fh.write("%d %d\n\n" % (es.nEnergySamples, es.nEnergies))
+                fh.write(row(es.energiesPerU) + "\n\n" + row(es.peakDepths) + "\n\n" + row(es.scaleFacts) + "\n\n")
+                for r in es.nucWeightMatrix:
+                    fh.write(row(r) + "\n")
+                fh.write("\n")
+                for r in es.nucSqSigmaMatrix:
+                    fh.write(row(r) + "\n")
 
 
 def _bragg_rows(energies, peaks, n_samples, peak_sample):
@@ -146,8 +177,9 @@ def _bragg_rows(energies, peaks, n_samples, peak_sample):
     return rows
 
 
-def synth_luts(n_energies=147, n_samples=1024, n_hu=3072, seed=0):
-    """Synthetic EnergyStruct with the shapes of the reference tables (1024x147, 3x3072)."""
+def synth_luts(n_energies=147, n_samples=1024, n_hu=3072, seed=0, nuclear=False):
+    """Synthetic EnergyStruct with the shapes of the reference tables (1024x147, 3x3072). nuclear: also the two NUCLEAR_CORR
+    tables — a halo fraction that grows with depth up to the peak (0..~12 %) and a squared halo sigma that grows with depth."""
     del seed  # tables are deterministic
     peaks = np.linspace(30.0, 320.0, n_energies)
     energies = (peaks / 0.01765) ** (1.0 / 1.8104)         # range-energy fit R = a E^p
@@ -162,4 +194,9 @@ def synth_luts(n_energies=147, n_samples=1024, n_hu=3072, seed=0):
                   1.0 + (hu - 1000) * (1.747 - 1.0) / (n_hu - 1 - 1000))
     rho = np.arange(n_hu, dtype=np.float64) / 1000.0        # density * 1000 index
     rrl = 0.00277 * (0.93 + 0.07 * np.clip(rho, 0, None)) + 0.0002 * np.clip(rho - 1.0, 0, None) ** 2
-    return EnergyStruct(energies, peaks, scale, cidd, 1.0, dens, 1.0, sp, 1000.0, rrl)
+    nw = nq = None
+    if nuclear:
+        frac = np.arange(n_samples, dtype=np.float64)[None, :] / peak_sample           # depth / peak depth
+        nw = 0.12 * np.clip(frac, 0.0, 1.0) * (peaks[:, None] / peaks.max()) ** 0.5
+        nq = (0.023 * peaks[:, None] * np.clip(frac, 0.0, 1.3)) ** 2 + 1.0
+    return EnergyStruct(energies, peaks, scale, cidd, 1.0, dens, 1.0, sp, 1000.0, rrl, nw, nq)

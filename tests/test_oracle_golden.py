@@ -128,3 +128,44 @@ def test_g7_cpu_convolution_weights(orc):
         L.orc_x_conv_cpu(P(imp), P(resp), C.c_float(rs), rad, 2 * rad + 1, 2 * rad + 1, 1, 0)
         np.testing.assert_array_equal(resp[0, rad + 1:], e[1:])          # same expression for i >= 1
         np.testing.assert_allclose(resp[0, rad], e[0], rtol=1.2e-7)      # erf(r/2) vs 0.5*(erf(r/2)+erf(r/2))
+
+
+# ---- G1n: NUCLEAR_CORR tables (energy_reader.cpp:103-162), pinned by one reference build per variant -------------------
+@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("parser", ["oracle", "python"])
+def test_g1n_nuclear_tables_small_dir(orc, variant, parser):
+    g = np.load(os.path.join(GOLDEN, "golden_g1n_nuclear_lut.npz"))
+    d = os.path.join(GOLDEN, "lut_small_nuc") + "/"
+    if parser == "oracle":
+        L = orc.lib()
+        s = abi.RtdLuts()
+        assert L.orc_read_luts_nuc(d.encode(), 0, variant, C.byref(s)) == 0
+        n = s.n_energies * s.n_energy_samples
+        w, q = np.ctypeslib.as_array(s.nuc_weight_matrix, (n,)).copy(), np.ctypeslib.as_array(s.nuc_sq_sigma_matrix, (n,)).copy()
+        L.orc_luts_free(C.byref(s))
+    else:
+        es = luts.read_lut_dir(d, False, nuclear_corr=variant)
+        w, q = es.nucWeightMatrix.reshape(-1), es.nucSqSigmaMatrix.reshape(-1)
+    np.testing.assert_array_equal(w, g["small_%d_weight" % variant])
+    np.testing.assert_array_equal(q, g["small_%d_sqsigma" % variant])
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3])
+def test_g1n_nuclear_tables_of_the_reference(orc, variant):
+    """The reference's real nuclear tables (read where they lie; skipped where /root/reference is absent): sizes, checksums, ends."""
+    if not os.path.isdir(REF_LUTS):
+        pytest.skip("reference LUTs not present")
+    g = np.load(os.path.join(GOLDEN, "golden_g1n_nuclear_lut.npz"))
+    es = luts.read_lut_dir(REF_LUTS, False, nuclear_corr=variant)
+    L = orc.lib()
+    s = abi.RtdLuts()
+    assert L.orc_read_luts_nuc(REF_LUTS.encode(), 0, variant, C.byref(s)) == 0
+    n = s.n_energies * s.n_energy_samples
+    for nm, py, oc in (("weight", es.nucWeightMatrix.reshape(-1), np.ctypeslib.as_array(s.nuc_weight_matrix, (n,)).copy()),
+                       ("sqsigma", es.nucSqSigmaMatrix.reshape(-1), np.ctypeslib.as_array(s.nuc_sq_sigma_matrix, (n,)).copy())):
+        for a in (py, oc):
+            assert a.size == int(g["real_%d_%s_n" % (variant, nm)])
+            assert hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest() == str(g["real_%d_%s_sha256" % (variant, nm)])
+            np.testing.assert_array_equal(a[:4], g["real_%d_%s_head" % (variant, nm)])
+            np.testing.assert_array_equal(a[-4:], g["real_%d_%s_tail" % (variant, nm)])
+    L.orc_luts_free(C.byref(s))
