@@ -6,7 +6,8 @@ metric   Mvoxels/s of dose deposited: dose-grid voxels x fields / wall time of t
 workload N=1: C3 = 512^3 synthetic heterogeneous CT, one field, 10x10 spots x 20 energy layers, 512 tracer steps
          (BASELINE.json configs[2] — the configuration the metric is quoted on).
          N>1: one field per GPU (gantry angles 360/N apart, same CT replicated): weak scaling, per-GPU work fixed.
-step     N=1: restore the zero dose volume + all kernels of the field + rtd_field_finish (pipelined by one plan).
+step     N=1: all kernels of the field, its transfer WRITING the field's dose box into the volume that is zero elsewhere
+         (= a fresh zero volume + the field, without clearing anything) + rtd_field_finish (pipelined by one plan).
          N>1: every rank computes its field up to the beam's-eye-view (BEV) dose, ONE RCCL all-gather moves the packed BEV
          slabs (~10 MB each; the dose boxes they turn into are 60-83 MB), and every rank runs the fan -> dose transfer of EVERY
          field, in field order, into its own slab of the dose volume (plan.BevExchange). The plan's volume is left sharded by
@@ -148,7 +149,6 @@ def main():
     main_stream.synchronize()
     step_no = [0]
     in_flight = []                      # (step index, field) launched, not yet finished
-    last_writer = {}                    # dose volume index -> the field object whose last plan wrote into it
 
     def launch():
         """Launch one plan iteration (asynchronous). N=1: fresh dose volume + all kernels of the field. N>1: this rank's field up to
@@ -160,12 +160,10 @@ def main():
             d = doses[i % len(doses)]
             if streams is not None:
                 eng.set_stream(streams[i % n_streams].cuda_stream)
-            # fresh dose volume: only the voxels the previous plan wrote are cleared (rtd_field_clear_dose), not all 512^3
-            v = i % len(doses)
-            if v in last_writer:
-                last_writer[v].clear_dose(d.data_ptr())
-            f.compute(d.data_ptr())
-            last_writer[v] = f
+            # fresh dose volume: the volume is zero outside the box the previous plan (same field geometry) wrote, so the field's
+            # transfer WRITES its dose box (rtd_field_transfer_init) — no clear of 512^3, no clear of the box, no read-modify-write
+            f.compute_bev()
+            f.transfer_init(d.data_ptr())
         else:
             b = i % 2
             if i >= 2:

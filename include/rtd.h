@@ -240,6 +240,10 @@ int rtd_field_release(rtd_handle h, rtd_field f);
  */
 int rtd_field_compute_bev(rtd_handle h, rtd_field f);
 int rtd_field_transfer(rtd_handle h, rtd_field f, float* dev_dose, const int32_t clip_min[3], const int32_t clip_max[3]);
+/* rtd_field_transfer for the FIRST field of a plan, into a volume that is zero everywhere except possibly inside this
+ * field's dose box (e.g. the volume the same field was transferred into by the previous plan): the box is written — dose
+ * or zero — instead of accumulated into, which replaces rtd_field_clear_dose + the read half of the read-modify-write. */
+int rtd_field_transfer_init(rtd_handle h, rtd_field f, float* dev_dose, const int32_t clip_min[3], const int32_t clip_max[3]);
 int rtd_field_wait_plan(rtd_handle h, rtd_field f, rtd_field_info* info, size_t* packed_bytes);
 size_t rtd_bev_message_bound(rtd_handle h, rtd_field f);
 int rtd_field_export_bev(rtd_handle h, rtd_field f, void* dev_buf, size_t capacity);

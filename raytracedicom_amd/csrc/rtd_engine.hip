@@ -750,7 +750,16 @@ static ClipBox makeClip(const int32_t* lo, const int32_t* hi) {
 
 // Part 2: fan -> dose-grid transfer (:1185-1218) of the field's BEV dose — its own, or the slab another GPU exported —
 // into dev_dose, optionally restricted to a box of the dose grid (a GPU's slab of the plan's volume).
+static int transferImpl(rtd_handle hh, rtd_field ff, float* dev_dose, const int32_t clip_min[3], const int32_t clip_max[3], bool init);
 int rtd_field_transfer(rtd_handle hh, rtd_field ff, float* dev_dose, const int32_t clip_min[3], const int32_t clip_max[3]) {
+    return transferImpl(hh, ff, dev_dose, clip_min, clip_max, false);
+}
+// The same transfer for the FIRST field into a volume that is zero everywhere except possibly inside this field's dose box: the
+// box is written (dose or zero), not accumulated into — no separate clear, no read of the old values.
+int rtd_field_transfer_init(rtd_handle hh, rtd_field ff, float* dev_dose, const int32_t clip_min[3], const int32_t clip_max[3]) {
+    return transferImpl(hh, ff, dev_dose, clip_min, clip_max, true);
+}
+static int transferImpl(rtd_handle hh, rtd_field ff, float* dev_dose, const int32_t clip_min[3], const int32_t clip_max[3], bool init) {
     auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
     auto* f = reinterpret_cast<rtd_field_impl*>(ff);
     if (!h || !f || !dev_dose) return RTD_ERR_INVALID_ARG;
@@ -774,16 +783,25 @@ int rtd_field_transfer(rtd_handle hh, rtd_field ff, float* dev_dose, const int32
         };
         // lanes run along the dose axis that moves fastest along BEV x, so that the gathers stay within few BEV rows
         hipEvent_t e0 = f->remote ? f->ev[0] : nullptr, e1 = halo ? nullptr : f->ev[6];
-        switch (f->transferMode) {
-            case 0: launchT(k_transfer, bev, st, e0, e1); break;
-            case 1: launchT(k_transfer_t<1>, bev, st, e0, e1); break;
-            default: launchT(k_transfer_t<2>, bev, st, e0, e1); break;
+        if (init && halo) return fail(h, RTD_ERR_INVALID_ARG, "rtd_field_transfer_init: not with nuclear_corr (the halo's box differs from the primary's)");
+        if (init) {
+            switch (f->transferMode) {
+                case 0: launchT((k_transfer<true>), bev, st, e0, e1); break;
+                case 1: launchT((k_transfer_t<1, true>), bev, st, e0, e1); break;
+                default: launchT((k_transfer_t<2, true>), bev, st, e0, e1); break;
+            }
+        } else {
+            switch (f->transferMode) {
+                case 0: launchT((k_transfer<false>), bev, st, e0, e1); break;
+                case 1: launchT((k_transfer_t<1, false>), bev, st, e0, e1); break;
+                default: launchT((k_transfer_t<2, false>), bev, st, e0, e1); break;
+            }
         }
         if (halo) {   // NUCLEAR_CORR: nucTransfDiv (kernel_wrapper.cu:100-127, launch :1221-1254) after the primary transfer, like the reference
             switch (f->transferModeNuc) {
-                case 0: launchT(k_transfer, (const float*)f->dNucBev, (const FieldState*)f->dStateNuc, nullptr, f->ev[6]); break;
-                case 1: launchT(k_transfer_t<1>, (const float*)f->dNucBev, (const FieldState*)f->dStateNuc, nullptr, f->ev[6]); break;
-                default: launchT(k_transfer_t<2>, (const float*)f->dNucBev, (const FieldState*)f->dStateNuc, nullptr, f->ev[6]); break;
+                case 0: launchT((k_transfer<false>), (const float*)f->dNucBev, (const FieldState*)f->dStateNuc, nullptr, f->ev[6]); break;
+                case 1: launchT((k_transfer_t<1, false>), (const float*)f->dNucBev, (const FieldState*)f->dStateNuc, nullptr, f->ev[6]); break;
+                default: launchT((k_transfer_t<2, false>), (const float*)f->dNucBev, (const FieldState*)f->dStateNuc, nullptr, f->ev[6]); break;
             }
         }
     }

@@ -1474,6 +1474,9 @@ __global__ __launch_bounds__(256) void k_superpose_reduce(const float* __restric
 // column and z-chunk inside the device-side bounding box (getFanIdx(z) is closed-form, so z splits freely).
 struct ClipBox { int lo[3], hi[3]; };          // inclusive dose-index box a transfer / clear is restricted to (a GPU's slab of the volume)
 
+// INIT: the voxels of the field's dose box are WRITTEN (dose or zero) instead of accumulated into: the first field of a plan
+// then needs neither a cleared box nor the read half of the read-modify-write (rtd_field_transfer_init).
+template <bool INIT>
 __global__ __launch_bounds__(256) void k_transfer(float* __restrict__ dose, int nx, int ny, int nz,
                                                    const float* __restrict__ bevDose, const FieldState* __restrict__ st,
                                                    FieldConst fc, int zChunk, ClipBox clip) {
@@ -1521,7 +1524,10 @@ __global__ __launch_bounds__(256) void k_transfer(float* __restrict__ dose, int 
                 }
             }
 #pragma unroll
-            for (int u = 0; u < kZU; ++u) if (tmp[u] > 0.0f) res[u * nxy] += tmp[u];
+            for (int u = 0; u < kZU; ++u) {
+                if (INIT) { if (z + u <= z1) res[u * nxy] = tmp[u] > 0.0f ? tmp[u] : 0.0f; }
+                else if (tmp[u] > 0.0f) res[u * nxy] += tmp[u];
+            }
             res += kZU * nxy;
         }
     }
@@ -1532,7 +1538,7 @@ __global__ __launch_bounds__(256) void k_transfer(float* __restrict__ dose, int 
 // Here the lanes of the gather phase run along the dose axis B (1 = y, 2 = z) that maps to BEV x; the values cross an LDS
 // tile and are added to the dose with lanes along x again. Per voxel the arithmetic is that of k_transfer.
 // (Gathering 8 x 8 patches of the (x, B) plane per wave for oblique beams measured within 3 % of this kernel at 45 degrees.)
-template <int B>
+template <int B, bool INIT>
 __global__ __launch_bounds__(256) void k_transfer_t(float* __restrict__ dose, int nx, int ny, int nz,
                                                      const float* __restrict__ bevDose, const FieldState* __restrict__ st,
                                                      FieldConst fc, int cChunk, ClipBox clip) {
@@ -1587,7 +1593,8 @@ __global__ __launch_bounds__(256) void k_transfer_t(float* __restrict__ dose, in
 #pragma unroll
             for (int u = 0; u < kZU; ++u) {
                 const float v = tile[buf][u][aB][aX];
-                if (aIn && v > 0.0f) res[u * strideC] += v;
+                if (INIT) { if (aIn && c + u <= c1) res[u * strideC] = v > 0.0f ? v : 0.0f; }
+                else if (aIn && v > 0.0f) res[u * strideC] += v;
             }
             res += kZU * strideC;
             buf ^= 1;                                                // the other tile is free: its readers passed the barrier above

@@ -66,6 +66,7 @@ def lib():
         i3 = C.POINTER(C.c_int32)
         L.rtd_field_compute_bev.argtypes = [vp, vp]
         L.rtd_field_transfer.argtypes = [vp, vp, vp, i3, i3]
+        L.rtd_field_transfer_init.argtypes = [vp, vp, vp, i3, i3]
         L.rtd_field_wait_plan.argtypes = [vp, vp, C.POINTER(abi.RtdFieldInfo), C.POINTER(C.c_size_t)]
         L.rtd_bev_message_bound.argtypes = [vp, vp]
         L.rtd_bev_message_bound.restype = C.c_size_t
@@ -128,6 +129,11 @@ class Field:
         to the inclusive dose-index box [clip_min, clip_max]; asynchronous."""
         lo, hi = self._clip(clip_min, clip_max)
         self.eng._check(lib().rtd_field_transfer(self.eng._h, self._h, C.c_void_p(int(dev_dose)), lo, hi))
+
+    def transfer_init(self, dev_dose, clip_min=None, clip_max=None):
+        """transfer() for the first field of a plan: the field's dose box is written (dose or zero), not accumulated into."""
+        lo, hi = self._clip(clip_min, clip_max)
+        self.eng._check(lib().rtd_field_transfer_init(self.eng._h, self._h, C.c_void_p(int(dev_dose)), lo, hi))
 
     def wait_plan(self):
         """(info, packed_bytes) once the device-side plan of the field is known (the superposition may still be running)."""

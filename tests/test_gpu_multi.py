@@ -61,6 +61,38 @@ def test_bev_then_transfer_equals_compute(engine, synth):
             eng.device_free(p)
 
 
+@pytest.mark.parametrize("deg", [0.0, 90.0, 52.0])
+def test_transfer_init_writes_the_box(engine, synth, deg):
+    """rtd_field_transfer_init into a volume holding stale values inside the field's dose box (and zeros elsewhere) == a transfer
+    into a zeroed volume, bit for bit (plain and transposed kernels)."""
+    scn = _scn(synth, angles=(deg,), dist=(1900.0, 2100.0))
+    n = scn.n_voxels
+    with engine.Engine(0) as eng:
+        eng.set_luts(scn.luts)
+        eng.set_ct(scn.ct)
+        f = eng.create_field(scn.beams[0], scn.dims)
+        a, b = eng.device_alloc(4 * n), eng.device_alloc(4 * n)
+        eng.device_zero(a, 4 * n)
+        eng.device_zero(b, 4 * n)
+        f.compute(a)
+        _, info = f.finish()
+        want = np.empty_like(scn.ct)
+        eng.to_host(want, a)
+        lo, hi = info["dose_box_min"], info["dose_box_max"]
+        stale = np.zeros_like(scn.ct)
+        stale[lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1] = 7.5            # garbage inside the box only
+        eng.to_device(b, stale)
+        f.compute_bev()
+        f.transfer_init(b)
+        f.finish()
+        got = np.empty_like(scn.ct)
+        eng.to_host(got, b)
+        assert want.max() > 0
+        np.testing.assert_array_equal(got, want)
+        f.destroy()
+        eng.device_free(a); eng.device_free(b)
+
+
 @pytest.mark.parametrize("deg,dist", [(0.0, (math.inf, math.inf)), (90.0, (1800.0, 2200.0)), (141.0, (math.inf, math.inf))])
 def test_exported_bev_slab_transfers_identically_on_another_handle(engine, synth, deg, dist):
     """The message [state record | non-zero block of the BEV dose] attached to a geometry-only field on ANOTHER handle gives the
