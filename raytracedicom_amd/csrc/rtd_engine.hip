@@ -81,6 +81,7 @@ struct rtd_field_impl {
     // device workspace
     float *dSpotWeights = nullptr, *dConvInterm = nullptr, *dRayWeights = nullptr;
     float *dDensity = nullptr, *dWepl = nullptr, *dRrl = nullptr, *dIdd = nullptr, *dRSigma = nullptr, *dBev = nullptr, *dBevPart = nullptr;
+    int* dNodeCount = nullptr;   // [output tile][step][32] arrival counters of the superposition's reduction tree (all zero between launches)
     int *dFirstInside = nullptr, *dFirstOutside = nullptr, *dFirstPassive = nullptr, *dWeplMin = nullptr;
     float* dBlockWeplMin = nullptr;   // [R/64][S] per scan block and step: smallest WEPL of the block's 64 rays
     unsigned char* dTileRad = nullptr;
@@ -418,7 +419,7 @@ int rtd_field_destroy(rtd_handle hh, rtd_field ff) {
     if (!h || !f) return RTD_ERR_INVALID_ARG;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = { f->dSpotWeights, f->dConvInterm, f->dRayWeights, f->dDensity, f->dWepl, f->dRrl, f->dIdd, f->dRSigma, f->dBev, f->dBevPart,
+    void* ptrs[] = { f->dSpotWeights, f->dConvInterm, f->dRayWeights, f->dDensity, f->dWepl, f->dRrl, f->dIdd, f->dRSigma, f->dBev, f->dBevPart, f->dNodeCount,
                      f->dFirstInside, f->dFirstOutside, f->dFirstPassive, f->dWeplMin, f->dBlockWeplMin, f->dTileRad,
                      f->dLayers, f->dState, f->dStepTab, f->dActive, f->dFillDbg,
                      f->dNucSpotIdx, f->dNucRayWeights, f->dNucIdd, f->dNucRs, f->dNucBev, f->dNucEffT, f->dStateNuc };
@@ -568,7 +569,7 @@ static int createField(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dim
     if (husk) {
         f->dSpotWeights = husk->dSpotWeights; f->dConvInterm = husk->dConvInterm; f->dRayWeights = husk->dRayWeights;
         f->dDensity = husk->dDensity; f->dWepl = husk->dWepl; f->dRrl = husk->dRrl; f->dIdd = husk->dIdd; f->dRSigma = husk->dRSigma;
-        f->dBev = husk->dBev; f->dBevPart = husk->dBevPart; f->dFirstInside = husk->dFirstInside; f->dFirstOutside = husk->dFirstOutside;
+        f->dBev = husk->dBev; f->dBevPart = husk->dBevPart; f->dNodeCount = husk->dNodeCount; f->dFirstInside = husk->dFirstInside; f->dFirstOutside = husk->dFirstOutside;
         f->dFirstPassive = husk->dFirstPassive; f->dWeplMin = husk->dWeplMin; f->dBlockWeplMin = husk->dBlockWeplMin; f->dTileRad = husk->dTileRad; f->dLayers = husk->dLayers;
         f->dState = husk->dState; f->dStepTab = husk->dStepTab; f->dActive = husk->dActive; f->hState = husk->hState; f->dHostState = husk->dHostState;
         for (int i = 0; i < 9; ++i) f->ev[i] = husk->ev[i];
@@ -578,7 +579,9 @@ static int createField(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dim
     int st = RTD_OK;
     auto A = [&](auto** p, size_t n) { if (st == RTD_OK && fresh) st = devAlloc(h, p, n); };
     A(&f->dSpotWeights, nSpot); A(&f->dConvInterm, (size_t)W * b->spot_ny * L); A(&f->dRayWeights, R * L);
-    A(&f->dDensity, R * S); A(&f->dWepl, R * S); A(&f->dRrl, R * S); A(&f->dIdd, R * S * L); A(&f->dRSigma, R * S * L); A(&f->dBev, P * S); A(&f->dBevPart, P * S * f->ksGroups);
+    A(&f->dDensity, R * S); A(&f->dWepl, R * S); A(&f->dRrl, R * S); A(&f->dIdd, R * S * L); A(&f->dRSigma, R * S * L); A(&f->dBev, P * S);
+    const size_t nOutTiles = (size_t)((fc.bevW + kKsTileX - 1) / kKsTileX) * ((fc.bevH + kKsTileY - 1) / kKsTileY);
+    A(&f->dBevPart, nOutTiles * kKsTileX * kKsTileY * S * f->ksGroups); A(&f->dNodeCount, nOutTiles * S * 32);
     A(&f->dFirstInside, R); A(&f->dFirstOutside, R); A(&f->dFirstPassive, R * L); A(&f->dWeplMin, (size_t)S); A(&f->dBlockWeplMin, (R / 64) * (size_t)S);
     A(&f->dTileRad, f->tileRadWords * 4); A(&f->dLayers, (size_t)L); A(&f->dState, (size_t)1); A(&f->dStepTab, (size_t)2 * S); A(&f->dActive, (size_t)4 * L * S);
     if (st != RTD_OK) { rtd_field_destroy(hh, reinterpret_cast<rtd_field>(f)); return st; }
@@ -634,6 +637,7 @@ static int createField(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dim
     // (the transfer reads the slices [entry, passive) only, and the superposition's reduce writes every pixel of those: slices
     //  outside hold stale values that nothing samples; a fresh buffer is cleared once so that a fetch of "bev" reads zeros there)
     if (fresh) e = hipMemset(f->dBev, 0, P * (size_t)S * sizeof(float));
+    if (fresh && e == hipSuccess) e = hipMemset(f->dNodeCount, 0, nOutTiles * (size_t)S * 32 * sizeof(int));
     if (e != hipSuccess) { h->error = std::string("HIP error: ") + hipGetErrorString(e); rtd_field_destroy(hh, reinterpret_cast<rtd_field>(f)); return RTD_ERR_HIP; }
     *out = reinterpret_cast<rtd_field>(f);
     return RTD_OK;
@@ -728,13 +732,11 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
         // few layers -> few, long work items: deal each item's chunks to 2 or 4 waves (the live items are a fraction of nItems)
         const int split = nItems >= 48 * 1024 ? 1 : (nItems >= 20 * 1024 ? 2 : 4);
         auto launchKs = [&](auto kernel) {
-            launchK(kernel, dim3(nItems), dim3(64 * split), 0, s, ev(8), ev(7), (const float*)f->dIdd, (const float*)f->dRSigma,
+            launchK(kernel, dim3(nItems), dim3(64 * split), 0, s, ev(8), f->ev[5], (const float*)f->dIdd, (const float*)f->dRSigma,
                     f->dBevPart, (const unsigned char*)f->dTileRad, (const LayerPlan*)f->dLayers, (const FieldState*)f->dState, fc, nTX, nTY, G,
-                    (const int*)f->dActive);
+                    (const int*)f->dActive, f->dBev, f->dNodeCount);
         };
         if (split == 1) launchKs(k_superpose_mfma<1>); else if (split == 2) launchKs(k_superpose_mfma<2>); else launchKs(k_superpose_mfma<4>);
-        launchK(k_superpose_reduce, dim3(1024), dim3(256), 0, s, nullptr, f->ev[5], (const float*)f->dBevPart, f->dBev,
-                              (const FieldState*)f->dState, fc, G);
     }
     RTD_HIP(h, hipGetLastError());
     f->computed = true;
@@ -926,10 +928,10 @@ int rtd_field_finish(rtd_handle hh, rtd_field ff, rtd_timing* timing, rtd_field_
             RTD_HIP(h, hipEventElapsedTime(&timing->fill_idd_sigma_ms, f->ev[2], f->ev[3]));
             RTD_HIP(h, hipEventElapsedTime(&timing->prepare_superp_ms, f->ev[3], f->ev[4]));
             RTD_HIP(h, hipEventElapsedTime(&timing->superp_ms, f->ev[4], f->ev[5]));
-            RTD_HIP(h, hipEventElapsedTime(&timing->superp_kernel_ms, f->ev[8], f->ev[7]));
+            RTD_HIP(h, hipEventElapsedTime(&timing->superp_kernel_ms, f->ev[8], f->ev[5]));
             if (f->transferred) RTD_HIP(h, hipEventElapsedTime(&timing->transforming_ms, f->ev[5], f->ev[6]));
         }
-        timing->superp_launches = 2;   // k_superpose_mfma + k_superpose_reduce (the reference: up to 33 per layer)
+        timing->superp_launches = 1;   // k_superpose_mfma, all layers and radii (the reference: up to 33 launches per layer)
         timing->ray_dims[0] = (uint32_t)f->fc.W; timing->ray_dims[1] = (uint32_t)f->fc.H;
         timing->steps = (uint32_t)f->fc.S; timing->n_layers = (uint32_t)f->fc.L;
         timing->transfer_voxels = 1;

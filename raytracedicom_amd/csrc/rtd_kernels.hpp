@@ -1136,8 +1136,8 @@ __global__ __launch_bounds__(256) void k_nuc_superpose(const float* __restrict__
 // reaches (own batch radius), builds the weight tables of the chunk into its private LDS slice (one source per lane,
 // the erfDiffs weights of kernel_wrapper.cuh:459-467), then issues one MFMA per (source quad, 16x16 tile) pair in the
 // quad's reach mask. No block barrier, no float atomics (the reference's flush, kernel_wrapper.cuh:486), no zero-fill
-// pass (kernel_wrapper.cu:824-827): each partial element is stored once and k_superpose_reduce adds the G partials
-// in fixed order, so the BEV dose is bitwise reproducible.
+// pass (kernel_wrapper.cu:824-827): the groups' accumulators are added in a fixed binary tree inside this launch (epilogue),
+// so the BEV dose is bitwise reproducible.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 // kKsSplit (template parameter of the kernel) = waves per work item: its source chunks are dealt round-robin to them and the
 // accumulators are summed through LDS at the end, in fixed order. 1 (single-wave blocks) when there are enough items to fill the
@@ -1154,7 +1154,8 @@ template <int kKsSplit>
 __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float* __restrict__ bevIdd, const float* __restrict__ bevRSigmaEff,
                                                             float* __restrict__ bevPart, const unsigned char* __restrict__ tileRad,
                                                             const LayerPlan* __restrict__ layers, const FieldState* __restrict__ st,
-                                                            FieldConst fc, int nTX, int nTY, int G, const int* __restrict__ active) {
+                                                            FieldConst fc, int nTX, int nTY, int G, const int* __restrict__ active,
+                                                            float* __restrict__ bevDose, int* __restrict__ nodeCount) {
     constexpr int kSlice = kKsWaveLds + kKsReachTiles;
     static_assert(kKsSplit == 1 || kKsSplit * kSlice >= 2048, "the accumulator exchange needs 2048 floats of LDS");
     __shared__ __attribute__((aligned(16))) float ldsAll[kKsSplit * kSlice];
@@ -1177,11 +1178,22 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
     const int first = st->beamFirstInside, calcPassive = st->firstCalculatedPassive;
     if (st->errorFlags) return;                                      // radius overflow: the reference throws before any superposition (kernel_wrapper.cu:965)
     if (k < 0 || k < first || k >= calcPassive) return;
-    if (k >= st->groupPassive[g]) return;                             // no layer of this group deposits at k: the reduce skips this partial
     const int li = lane & 15, kq = lane >> 4;                         // MFMA 16x16x4: A[i=li][k=kq], B[k=kq][j=li]
     const int ox0 = tX * kKsTileX, oy0 = tY * kKsTileY;               // padded BEV coordinates of the owned tile
-    // a tile outside the rectangle that any patch of the field can reach stays unwritten: k_superpose_reduce does not read it
-    if (ox0 > st->bevHi[0] || ox0 + kKsTileX - 1 < st->bevLo[0] || oy0 > st->bevHi[1] || oy0 + kKsTileY - 1 < st->bevLo[1]) return;
+    // A tile outside the rectangle that any patch of the field can reach receives nothing: one item per (tile, slice) writes its
+    // zeros into the BEV dose (the transfer interpolates against the pixels next to the rectangle).
+    if (ox0 > st->bevHi[0] || ox0 + kKsTileX - 1 < st->bevLo[0] || oy0 > st->bevHi[1] || oy0 + kKsTileY - 1 < st->bevLo[1]) {
+        if (gi == 0 && wv == 0) {
+            float* dst = bevDose + (size_t)k * fc.bevW * fc.bevH;
+#pragma unroll
+            for (int e = 0; e < 32; ++e) {
+                const int oy = oy0 + 16 * (e >> 4) + 4 * kq + (e & 3), ox = ox0 + 16 * ((e >> 2) & 3) + li;
+                if (oy < fc.bevH && ox < fc.bevW) dst[(size_t)oy * fc.bevW + ox] = 0.0f;
+            }
+        }
+        return;
+    }
+    if (k >= st->groupPassive[g]) return;                             // no layer of this group deposits at k
     const int W = fc.W, H = fc.H;
     const size_t memStep = (size_t)W * H;
     const int nTiles = fc.tilesX * fc.tilesY;
@@ -1424,8 +1436,46 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
         }
         if (wv != 0) return;
     }
-    // ---- epilogue: one plain store per partial element; D[row=(lane>>4)*4+reg][col=lane&15] ----
-    float* out = bevPart + ((size_t)g * fc.S + k) * fc.bevW * fc.bevH;
+    // ---- epilogue: the BEV dose of (tile, slice k) is the sum over the layer groups that deposit at k. ----
+    // No second pass over the partials: the groups' accumulators are added in a fixed binary tree over the ranks of the active
+    // groups. At every node the LATER of the two arriving waves does the addition (a + b = b + a exactly, so the result does not
+    // depend on who that is: bitwise reproducible), the earlier one has left its data in a slot and exits. Hand-off between
+    // waves on different XCDs (L2s are not coherent with each other): the data stores and loads are agent-scope (sc1: at the
+    // memory side), drained with s_waitcnt vmcnt(0) before the node counter (an atomic at the memory side) is touched —
+    // MI355X_MICROARCH.md, "Correctness boundaries". A wave never waits for another: every item runs to its end on its own.
+    int nAct = 0, rank = 0;
+    for (int g2 = 0; g2 < G; ++g2) { const int a = k < st->groupPassive[g2] ? 1 : 0; nAct += a; rank += (g2 < g) ? a : 0; }
+    constexpr int kSlotFloats = kKsTileX * kKsTileY;                 // 2048: [element 0..31][lane]
+    const size_t nT = (size_t)nTX * nTY;
+    int* cnt = nodeCount + ((size_t)tile * fc.S + k) * 32;
+    int level = 0, n = nAct;
+    while (n > 1) {
+        const int sib = rank ^ 1;
+        if (sib < n) {
+            float* mine = bevPart + (((size_t)(rank << level) * fc.S + k) * nT + tile) * kSlotFloats;
+#pragma unroll
+            for (int e = 0; e < 32; ++e) __hip_atomic_store(mine + e * 64 + lane, acc[e >> 4][(e >> 2) & 3][e & 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): the slot is complete at the memory side
+            int* node = cnt + (32 - (32 >> level)) + (rank >> 1);
+            int old = 0;
+            if (lane == 0) old = __hip_atomic_fetch_add(node, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            old = __builtin_amdgcn_readfirstlane(old);
+            if (old == 0) return;                                    // first at this node: the sibling takes over
+            if (lane == 0) __hip_atomic_store(node, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            const float* theirs = bevPart + (((size_t)(sib << level) * fc.S + k) * nT + tile) * kSlotFloats;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {                            // (in quarters: 8 loads in flight, within the kernel's 72 registers)
+                float t[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] = __hip_atomic_load(theirs + (8 * h + e) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[h >> 1][2 * (h & 1) + (e >> 2)][e & 3] += t[e];
+            }
+        }
+        rank >>= 1; n = (n + 1) >> 1; ++level;
+    }
+    // root: one plain store per element; D[row=(lane>>4)*4+reg][col=lane&15]
+    float* out = bevDose + (size_t)k * fc.bevW * fc.bevH;
 #pragma unroll
     for (int ty = 0; ty < 2; ++ty)
 #pragma unroll
@@ -1435,36 +1485,6 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
                 const int oy = oy0 + 16 * ty + 4 * kq + reg, ox = ox0 + 16 * tx + li;
                 if (oy < fc.bevH && ox < fc.bevW) out[(size_t)oy * fc.bevW + ox] = acc[ty][tx][reg];
             }
-}
-
-// K7b: BEV dose = sum of the layer-group partials in fixed order (slices outside [entry, passive) are not touched).
-__global__ __launch_bounds__(256) void k_superpose_reduce(const float* __restrict__ bevPart, float* __restrict__ bevDose,
-                                                           const FieldState* __restrict__ st, FieldConst fc, int G) {
-    const int first = st->beamFirstInside, calcPassive = st->firstCalculatedPassive;
-    if (st->errorFlags) return;
-    const size_t P = (size_t)fc.bevW * fc.bevH;
-    const size_t n4 = (size_t)(calcPassive > first ? calcPassive - first : 0) * P / 4;   // P is a multiple of 4 (bevW % 32 == 0)
-    const float4* p0 = reinterpret_cast<const float4*>(bevPart + (size_t)first * P);
-    float4* o = reinterpret_cast<float4*>(bevDose + (size_t)first * P);
-    const size_t gstride = (size_t)fc.S * P / 4;
-    const size_t P4 = P / 4;
-    // only the output tiles that intersect the reachable rectangle were written by k_superpose_mfma; the rest of a slice is zero
-    const int rx0 = (st->bevLo[0] / kKsTileX) * kKsTileX, rx1 = (st->bevHi[0] / kKsTileX) * kKsTileX + kKsTileX - 1;
-    const int ry0 = (st->bevLo[1] / kKsTileY) * kKsTileY, ry1 = (st->bevHi[1] / kKsTileY) * kKsTileY + kKsTileY - 1;
-    const int W4 = fc.bevW / 4;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        const int k = first + (int)(i / P4);
-        const int pix = (int)(i % P4), y = pix / W4, x = (pix - y * W4) * 4;
-        float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (x >= rx0 && x <= rx1 && y >= ry0 && y <= ry1) {
-            for (int gI = 0; gI < G; ++gI) {
-                if (k >= st->groupPassive[gI]) continue;             // this group's partial slice was not written (all zero)
-                const float4 b = p0[i + gI * gstride];
-                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-            }
-        }
-        o[i] = a;
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
