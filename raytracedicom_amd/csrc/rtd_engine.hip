@@ -704,14 +704,14 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
             f->fillDbgN = (size_t)4 * fillGrid.x;
             RTD_HIP(h, hipMalloc((void**)&f->dFillDbg, f->fillDbgN * sizeof(long long)));
         }
-        if (fillLds <= 40 * 1024)     // + ~17 KiB of static exchange arrays: stays under the 64 KiB default cap of a block's LDS
-            launchK((k_fill<true>), fillGrid, fillBlk, fillLds, s, nullptr, ev(3), (const float*)f->dDensity, (const float*)f->dWepl, (const float*)f->dRrl, f->dIdd,
-                                  f->dRSigma, (const float*)f->dRayWeights, (const int*)f->dFirstInside, (const int*)f->dFirstOutside,
-                                  f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc, (const float*)f->dStepTab, f->dActive, h->numCUs, f->dFillDbg, nucFill);
-        else
-            launchK((k_fill<false>), fillGrid, fillBlk, 0, s, nullptr, ev(3), (const float*)f->dDensity, (const float*)f->dWepl, (const float*)f->dRrl, f->dIdd,
-                                  f->dRSigma, (const float*)f->dRayWeights, (const int*)f->dFirstInside, (const int*)f->dFirstOutside,
-                                  f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc, (const float*)f->dStepTab, f->dActive, h->numCUs, f->dFillDbg, nucFill);
+        auto launchFill = [&](auto kern, size_t lds) {
+            launchK(kern, fillGrid, fillBlk, lds, s, nullptr, ev(3), (const float*)f->dDensity, (const float*)f->dWepl, (const float*)f->dRrl, f->dIdd,
+                    f->dRSigma, (const float*)f->dRayWeights, (const int*)f->dFirstInside, (const int*)f->dFirstOutside,
+                    f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc, (const float*)f->dStepTab, f->dActive, h->numCUs, f->dFillDbg, nucFill);
+        };
+        const bool ldsLut = fillLds <= 40 * 1024;     // + ~17 KiB of static exchange arrays: stays under the 64 KiB default cap of a block's LDS
+        if (fc.nuclearCorr) { if (ldsLut) launchFill((k_fill<true, true>), fillLds); else launchFill((k_fill<false, true>), 0); }
+        else { if (ldsLut) launchFill((k_fill<true, false>), fillLds); else launchFill((k_fill<false, false>), 0); }
     }
     if (fc.nuclearCorr) {
         // the halo's plan runs first: its radius overflow (kernel_wrapper.cu:984) is reported in the primary state, which k_ks_plan mirrors

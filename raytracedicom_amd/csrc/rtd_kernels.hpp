@@ -601,7 +601,8 @@ struct NucFill {
     float* idd; float* rs;         // [L][nucH][nucW] plane 0 of the reference's nuclear arrays after layer l
 };
 
-template <bool LDS_LUT>
+// NUC: NUCLEAR_CORR compiled in (its table lookups and IEEE divisions cost registers: the default build keeps 6 blocks per CU)
+template <bool LDS_LUT, bool NUC>
 __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensity, const float* __restrict__ bevCumulSp,
                                                const float* __restrict__ bevRrl,
                                                float* __restrict__ bevIdd, float* __restrict__ bevRSigmaEff,
@@ -666,9 +667,9 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
         if (tid < kMaxSuperpR + 2) sHist[tid] = 0;
         const float pInv = 0.5649718f, eCoef = 8.639415f;
         // E_s^2 and the empirical widening per NUCLEAR_CORR variant (kernel_wrapper.cu:228-245)
-        const float eRefSq = fc.nuclearCorr == 1 ? 190.44f : fc.nuclearCorr == 2 ? 216.09f : fc.nuclearCorr == 3 ? 169.00f : 198.81f;
-        const float sigmaDeltaV = fc.nuclearCorr == 1 ? 0.0f : fc.nuclearCorr == 2 ? 0.08f : fc.nuclearCorr == 3 ? 0.06f : 0.21f;
-        const int nucIdx = fc.nuclearCorr ? nuc.spotIdx[rayIdx] : -1;
+        const float eRefSq = !NUC ? 198.81f : fc.nuclearCorr == 1 ? 190.44f : fc.nuclearCorr == 2 ? 216.09f : fc.nuclearCorr == 3 ? 169.00f : 198.81f;
+        const float sigmaDeltaV = !NUC ? 0.21f : fc.nuclearCorr == 1 ? 0.0f : fc.nuclearCorr == 2 ? 0.08f : fc.nuclearCorr == 3 ? 0.06f : 0.21f;
+        const int nucIdx = NUC && fc.nuclearCorr ? nuc.spotIdx[rayIdx] : -1;
         const float entrySigmaSq = lp.entrySigmaX * lp.entrySigmaX;  // FillIddAndSigmaParams::getEntrySigmaSq (:925, 4th argument)
         float nucRSigmaEff = __int_as_float(0x7f800000);
         float rSigmaEff = 0.0f, incScat = 0.0f, incincScat = 0.0f;
@@ -706,13 +707,13 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
                         incScat += incincScat;
                         incDiv += 2.0f * lp.sigmaSqAirQuad;
                     } else {
-                        if (fc.nuclearCorr != 3) sigmaSq -= 1.5f * (incScat + incDiv) * density;   // (not for GAUSS_FIT, :300-302)
+                        if (!NUC || fc.nuclearCorr != 3) sigmaSq -= 1.5f * (incScat + incDiv) * density;   // (not for GAUSS_FIT, :300-302)
                     }
                     // stepTab[2k] = 0.5*(voxelWidth(k).x + voxelWidth(k).y): per-step constant evaluated once on the host with the
                     // reference's expressions (fill_idd_and_sigma_params.cu:42-46). Hardware sqrt / reciprocal: this value only
                     // weights the superposition; the radius class comes from sigmaSq itself (below).
                     rSigmaEff = stepTab[2 * stepNo] * __builtin_amdgcn_rcpf(sqrt2 * (__builtin_amdgcn_sqrtf(sigmaSq) + sigmaDeltaV));
-                    if (nucIdx >= 0) {                               // :332-341 (IEEE: its tile minimum becomes a radius class too)
+                    if (NUC && nucIdx >= 0) {                        // :332-341 (IEEE: its tile minimum becomes a radius class too)
                         const float nucSqSigma = sample2dClamp(lut.nucSqSigma, lut.nSamples, lut.nEnergies,
                                                                0.5f * (cumulSp + cumulSpOld) * lp.energyScaleFact, lp.energyIdx);
                         const Vec2 vw = fg.voxelWidth(stepNo);
@@ -746,7 +747,7 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
             }
         }
         firstPassive[(size_t)layer * memStep + rayIdx] = (int)afterLast;
-        if (nucIdx >= 0 && pFirst < pAfterLast) nuc.rs[(size_t)layer * fc.nucW * fc.nucH + nucIdx] = nucRSigmaEff;   // value of the last step (:367-373)
+        if (NUC && nucIdx >= 0 && pFirst < pAfterLast) nuc.rs[(size_t)layer * fc.nucW * fc.nucH + nucIdx] = nucRSigmaEff;   // value of the last step (:367-373)
         int mx = waveMaxI((int)afterLast);
         if ((tid & (kWave - 1)) == 0) atomicMax(&layers[layer].layerFirstPassive, mx);
         __syncthreads();
@@ -768,7 +769,7 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
         float* sRow1 = sLutF + lut.nSamples;
         if (LDS_LUT) for (int i = tid; i < lut.nSamples; i += 256) { sRow0[i] = gRow0[i]; sRow1[i] = gRow1[i]; }
         float res = 0.0f, cumulDoseOld = 0.0f;
-        const int nucIdx = fc.nuclearCorr ? nuc.spotIdx[rayIdx] : -1;
+        const int nucIdx = NUC && fc.nuclearCorr ? nuc.spotIdx[rayIdx] : -1;
         const float nucRayWeight = nucIdx >= 0 ? nuc.rayWeights[(size_t)layer * fc.nucW * fc.nucH + nucIdx] : 0.0f;
         float nucRes = 0.0f;
         int actUni = 0x7fffffff;
@@ -810,7 +811,7 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
                     const float stepVol = stepTab[2 * stepNo + 1];
                     const float mass = fc.doseToWater ? (cumulSp - cumulSpOld) * stepVol : density * stepVol;
                     // (the dose value feeds no threshold other than res > 0, which a reciprocal cannot change: hardware reciprocal, <= 1 ulp)
-                    if (!fc.nuclearCorr) {
+                    if (!NUC || !fc.nuclearCorr) {
                         if (mass > 1e-2f) res = rayWeight * (cumulDose - cumulDoseOld) * __builtin_amdgcn_rcpf(mass);
                     } else if (mass > 1e-2f) {                       // :320-331: the primary keeps (1 - nucWeight), the halo gets nucWeight
                         const float nucWeight = sample2dClamp(lut.nucWeight, lut.nSamples, lut.nEnergies,
@@ -852,7 +853,7 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
             }
         }
         if ((tid & 31) < 4 && actUni != 0x7fffffff) atomicMin(&st->actUnion[tid & 3], actUni);
-        if (nucIdx >= 0 && pFirst < pAfterLast) nuc.idd[(size_t)layer * fc.nucW * fc.nucH + nucIdx] = nucRes;   // value of the last step (:367-373)
+        if (NUC && nucIdx >= 0 && pFirst < pAfterLast) nuc.idd[(size_t)layer * fc.nucW * fc.nucH + nucIdx] = nucRes;   // value of the last step (:367-373)
     }
     if (dbg && tid == 0) {
         long long* q = dbg + 4 * (size_t)blockIdx.x;
