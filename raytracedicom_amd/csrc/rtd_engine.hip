@@ -51,11 +51,13 @@ struct rtd_handle_impl {
     bool haveLuts = false;
     std::vector<float> energiesPerU, peakDepths, scaleFacts;
     float densityScale = 0, spScale = 0, rrlScale = 0;
-    float* dLutBlock = nullptr;   // one allocation: cidd | density | sp | rrl
+    float* dLutBlock = nullptr;   // one allocation: cidd | density | sp | rrl (| nuclear weight | nuclear sigma^2)
+    size_t lutBlockFloats = 0;
     LutView lut{};
     // CT
     const float* dCt = nullptr;
     float* dCtOwned = nullptr;
+    size_t ctOwnedVoxels = 0;     // size of dCtOwned: a CT of the same size is uploaded in place (no free + malloc of the volume)
     uint32_t ctDims[3] = {0, 0, 0};
 };
 
@@ -305,8 +307,10 @@ int rtd_set_luts(rtd_handle hh, const rtd_luts* l) {   // kernel_wrapper.cu:453-
     RTD_HIP(h, hipSetDevice(h->device));
     const size_t nC = (size_t)l->n_energies * l->n_energy_samples, nD = l->n_density_samples, nS = l->n_sp_samples, nR = l->n_rrl_samples;
     const bool nuc = l->nuc_weight_matrix && l->nuc_sq_sigma_matrix;    // NUCLEAR_CORR tables (energy_struct.h:33-36), optional
-    if (h->dLutBlock) { RTD_HIP(h, hipStreamSynchronize(h->stream)); RTD_HIP(h, hipFree(h->dLutBlock)); h->dLutBlock = nullptr; }
-    RTD_HIP(h, hipMalloc((void**)&h->dLutBlock, (nC + nD + nS + nR + (nuc ? 2 * nC : 0)) * sizeof(float)));
+    const size_t lutFloats = nC + nD + nS + nR + (nuc ? 2 * nC : 0);
+    RTD_HIP(h, hipStreamSynchronize(h->stream));                     // no kernel still reads the tables that are replaced
+    if (h->dLutBlock && h->lutBlockFloats != lutFloats) { RTD_HIP(h, hipFree(h->dLutBlock)); h->dLutBlock = nullptr; }
+    if (!h->dLutBlock) { RTD_HIP(h, hipMalloc((void**)&h->dLutBlock, lutFloats * sizeof(float))); h->lutBlockFloats = lutFloats; }
     float* p = h->dLutBlock;
     RTD_HIP(h, hipMemcpy(p, l->cidd_matrix, nC * 4, hipMemcpyHostToDevice)); h->lut.cidd = p; p += nC;
     RTD_HIP(h, hipMemcpy(p, l->density_vector, nD * 4, hipMemcpyHostToDevice)); h->lut.density = p; p += nD;
@@ -394,7 +398,7 @@ int rtd_set_ct_device(rtd_handle hh, const float* dev, const uint32_t dims[3]) {
     auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
     if (!h || !dev || !dims || !dims[0] || !dims[1] || !dims[2]) return RTD_ERR_INVALID_ARG;
     RTD_HIP(h, hipSetDevice(h->device));
-    if (h->dCtOwned) { RTD_HIP(h, hipStreamSynchronize(h->stream)); RTD_HIP(h, hipFree(h->dCtOwned)); h->dCtOwned = nullptr; }
+    if (h->dCtOwned) { RTD_HIP(h, hipStreamSynchronize(h->stream)); RTD_HIP(h, hipFree(h->dCtOwned)); h->dCtOwned = nullptr; h->ctOwnedVoxels = 0; }
     h->dCt = dev;
     std::memcpy(h->ctDims, dims, sizeof h->ctDims);
     return RTD_OK;
@@ -405,8 +409,9 @@ int rtd_set_ct(rtd_handle hh, const float* host, const uint32_t dims[3]) {   // 
     if (!h || !host || !dims || !dims[0] || !dims[1] || !dims[2]) return RTD_ERR_INVALID_ARG;
     RTD_HIP(h, hipSetDevice(h->device));
     const size_t n = (size_t)dims[0] * dims[1] * dims[2];
-    if (h->dCtOwned) { RTD_HIP(h, hipStreamSynchronize(h->stream)); RTD_HIP(h, hipFree(h->dCtOwned)); h->dCtOwned = nullptr; }
-    RTD_HIP(h, hipMalloc((void**)&h->dCtOwned, n * sizeof(float)));
+    RTD_HIP(h, hipStreamSynchronize(h->stream));                     // no kernel still reads the volume that is replaced
+    if (h->dCtOwned && h->ctOwnedVoxels != n) { RTD_HIP(h, hipFree(h->dCtOwned)); h->dCtOwned = nullptr; }
+    if (!h->dCtOwned) { RTD_HIP(h, hipMalloc((void**)&h->dCtOwned, n * sizeof(float))); h->ctOwnedVoxels = n; }
     RTD_HIP(h, hipMemcpy(h->dCtOwned, host, n * sizeof(float), hipMemcpyHostToDevice));
     h->dCt = h->dCtOwned;
     std::memcpy(h->ctDims, dims, sizeof h->ctDims);
@@ -581,7 +586,8 @@ static int createField(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dim
     A(&f->dSpotWeights, nSpot); A(&f->dConvInterm, (size_t)W * b->spot_ny * L); A(&f->dRayWeights, R * L);
     A(&f->dDensity, R * S); A(&f->dWepl, R * S); A(&f->dRrl, R * S); A(&f->dIdd, R * S * L); A(&f->dRSigma, R * S * L); A(&f->dBev, P * S);
     const size_t nOutTiles = (size_t)((fc.bevW + kKsTileX - 1) / kKsTileX) * ((fc.bevH + kKsTileY - 1) / kKsTileY);
-    A(&f->dBevPart, nOutTiles * kKsTileX * kKsTileY * S * f->ksGroups); A(&f->dNodeCount, nOutTiles * S * 32);
+    A(&f->dBevPart, nOutTiles * kKsTileX * kKsTileY * S * f->ksGroups);
+    A(&f->dNodeCount, nOutTiles * S * 32);
     A(&f->dFirstInside, R); A(&f->dFirstOutside, R); A(&f->dFirstPassive, R * L); A(&f->dWeplMin, (size_t)S); A(&f->dBlockWeplMin, (R / 64) * (size_t)S);
     A(&f->dTileRad, f->tileRadWords * 4); A(&f->dLayers, (size_t)L); A(&f->dState, (size_t)1); A(&f->dStepTab, (size_t)2 * S); A(&f->dActive, (size_t)4 * L * S);
     if (st != RTD_OK) { rtd_field_destroy(hh, reinterpret_cast<rtd_field>(f)); return st; }
@@ -633,12 +639,12 @@ static int createField(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dim
         f->transferModeNuc = std::max(ay, az) > kTransferAxisRatio * ax ? (ay >= az ? 1 : 2) : 0;
     }
     if (fresh) for (auto& ev : f->ev) if (e == hipSuccess) e = hipEventCreate(&ev);
-    if (e != hipSuccess) { h->error = std::string("HIP error: ") + hipGetErrorString(e); rtd_field_destroy(hh, reinterpret_cast<rtd_field>(f)); return RTD_ERR_HIP; }
+    if (e != hipSuccess) { h->error = std::string("HIP error (field set-up): ") + hipGetErrorString(e); rtd_field_destroy(hh, reinterpret_cast<rtd_field>(f)); return RTD_ERR_HIP; }
     // (the transfer reads the slices [entry, passive) only, and the superposition's reduce writes every pixel of those: slices
     //  outside hold stale values that nothing samples; a fresh buffer is cleared once so that a fetch of "bev" reads zeros there)
     if (fresh) e = hipMemset(f->dBev, 0, P * (size_t)S * sizeof(float));
     if (fresh && e == hipSuccess) e = hipMemset(f->dNodeCount, 0, nOutTiles * (size_t)S * 32 * sizeof(int));
-    if (e != hipSuccess) { h->error = std::string("HIP error: ") + hipGetErrorString(e); rtd_field_destroy(hh, reinterpret_cast<rtd_field>(f)); return RTD_ERR_HIP; }
+    if (e != hipSuccess) { h->error = std::string("HIP error (clearing the BEV buffer / node counters): ") + hipGetErrorString(e); rtd_field_destroy(hh, reinterpret_cast<rtd_field>(f)); return RTD_ERR_HIP; }
     *out = reinterpret_cast<rtd_field>(f);
     return RTD_OK;
 }
