@@ -341,3 +341,30 @@ def test_field_launch_sequence_is_hipgraph_capturable(engine, synth):
     eng.set_stream(None)
     fld.destroy()
     eng.close()
+
+
+def test_reduction_tree_hand_offs_are_race_free_over_many_launches(engine, synth):
+    """The superposition adds the layer groups' accumulators in a tree whose hand-offs cross XCDs (agent-scope stores / loads, node
+    counters that the second arriver resets). 40 launches of the bench-sized field (14 groups, 15 output tiles, ~230 live slices:
+    ~40 k hand-offs per launch) must give the same BEV dose bit for bit, and the counters must be back at zero every time (a stale
+    slot or a lost arrival would change bits or leave a tile unwritten)."""
+    import zlib
+    ct, _ = scenarios.hetero_phantom(256)
+    scn = scenarios.hetero_ct(synth, n=256, angles=[0.0], ct=ct)      # same ray grid, layers and steps as the 512^3 bench field
+    with engine.Engine(0) as eng:
+        eng.set_luts(scn.luts)
+        eng.set_ct(scn.ct)
+        f = eng.create_field(scn.beams[0], scn.dims)
+        first = None
+        for it in range(40):
+            f.compute_bev()
+            f.finish()
+            bev = f.fetch("bev")
+            h = zlib.crc32(bev.tobytes())
+            if first is None:
+                first, ref = h, bev.copy()
+                assert ref.max() > 0
+            elif h != first:
+                bad = np.nonzero(bev.view(np.uint32) != ref.view(np.uint32))[0]
+                raise AssertionError("launch %d differs from launch 0 in %d BEV values (first at flat index %d)" % (it, bad.size, int(bad[0])))
+        f.destroy()
