@@ -291,6 +291,8 @@ int rtd_field_fetch(rtd_handle h, rtd_field f, const char* name, void* host_out,
  * 1356-1360) run in parallel as well. No dose data crosses between GPUs, and every voxel sees the same `+=` order as on one
  * GPU: the result equals rtd_compute bit for bit.
  * device_ids may repeat an id (several handles on one GPU) — used by the tests on one-GPU machines.
+ * Environment: RTD_PLAN_TRANSPORT=rccl moves the slabs with ncclBroadcast (communicators from ncclCommInitAll, librccl opened on
+ * demand; distinct device ids required) instead of peer copies.
  */
 typedef struct rtd_plan_s* rtd_plan_t;
 

@@ -15,15 +15,45 @@
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library is opened on demand (no link-time dependency)
+
 #include "../../include/rtd.h"
 
 namespace {
+
+// RCCL as the transport of the slab exchange (RTD_PLAN_TRANSPORT=rccl): one communicator per device of this process
+// (ncclCommInitAll), one ncclBroadcast per beam from the device that computed it — every device thread makes the call on its own
+// communicator and stream. librccl is dlopen'ed when asked for, so the default transport (peer copies) and every other entry point
+// of the engine carry no dependency on it (a process may already hold another copy, e.g. PyTorch's).
+struct RcclApi {
+    void* lib = nullptr;
+    decltype(&ncclCommInitAll) commInitAll = nullptr;
+    decltype(&ncclCommDestroy) commDestroy = nullptr;
+    decltype(&ncclBroadcast) broadcast = nullptr;
+    decltype(&ncclGetErrorString) errorString = nullptr;
+    bool load(std::string& err) {
+        if (lib) return true;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+        }
+        if (!lib) { err = std::string("RTD_PLAN_TRANSPORT=rccl: cannot open librccl: ") + dlerror(); return false; }
+        commInitAll = reinterpret_cast<decltype(commInitAll)>(dlsym(lib, "ncclCommInitAll"));
+        commDestroy = reinterpret_cast<decltype(commDestroy)>(dlsym(lib, "ncclCommDestroy"));
+        broadcast = reinterpret_cast<decltype(broadcast)>(dlsym(lib, "ncclBroadcast"));
+        errorString = reinterpret_cast<decltype(errorString)>(dlsym(lib, "ncclGetErrorString"));
+        if (!commInitAll || !commDestroy || !broadcast || !errorString) { err = "RTD_PLAN_TRANSPORT=rccl: librccl lacks an entry point"; return false; }
+        return true;
+    }
+};
 
 // reusable barrier of the device threads (std::barrier needs C++20)
 class Barrier {
@@ -58,6 +88,11 @@ double nowMs() { return std::chrono::duration<double, std::milli>(std::chrono::s
 struct rtd_plan_s {
     std::vector<DevSlot> dev;
     std::string error;
+    // RCCL transport (optional)
+    bool useRccl = false;
+    bool selfMessages = false;             // RTD_PLAN_SELF_MESSAGES: owners, too, transfer from the exchanged copy (exercises the transport on one GPU)
+    RcclApi rccl;
+    std::vector<ncclComm_t> comms;
 };
 
 // the same call on every device, in parallel (uploads of the replicated inputs overlap)
@@ -105,12 +140,28 @@ int rtd_plan_create(const int* device_ids, int n_devices, rtd_plan_t* out) {
                 if (hipDeviceEnablePeerAccess(db, 0) != hipSuccess) (void)hipGetLastError();   // already enabled is fine
             }
         }
+    // transport of the slab exchange: peer copies (default) or RCCL
+    const char* tr = std::getenv("RTD_PLAN_TRANSPORT");
+    if (tr && std::string(tr) == "rccl") {
+        for (int a = 0; a < n_devices; ++a)
+            for (int b = a + 1; b < n_devices; ++b)
+                if (device_ids[a] == device_ids[b]) { rtd_plan_destroy(p); return RTD_ERR_INVALID_ARG; }   // RCCL: one rank per GPU
+        if (!p->rccl.load(p->error)) { rtd_plan_destroy(p); return RTD_ERR_IO; }
+        p->comms.assign((size_t)n_devices, nullptr);
+        const ncclResult_t r = p->rccl.commInitAll(p->comms.data(), n_devices, device_ids);
+        if (r != ncclSuccess) { p->comms.clear(); rtd_plan_destroy(p); return RTD_ERR_HIP; }
+        p->useRccl = true;
+        const char* sm = std::getenv("RTD_PLAN_SELF_MESSAGES");
+        p->selfMessages = sm && sm[0] == '1';
+    }
     *out = p;
     return RTD_OK;
 }
 
 int rtd_plan_destroy(rtd_plan_t p) {
     if (!p) return RTD_ERR_INVALID_ARG;
+    for (ncclComm_t c : p->comms) if (c) (void)p->rccl.commDestroy(c);
+    p->comms.clear();
     for (DevSlot& s : p->dev) {
         if (!s.h) continue;
         (void)hipSetDevice(s.device);
@@ -189,7 +240,7 @@ int rtd_plan_compute(rtd_plan_t p, const rtd_beam* beams, int n_beams, float* do
         for (int i = d; i < n_beams && s.status == RTD_OK; i += D, ++slot) {
             if (bad(rtd_field_create(s.h, &beams[i], dose_dims, &mine[(size_t)i]))) break;
             if (bad(rtd_field_compute_bev(s.h, mine[(size_t)i]))) break;
-            if (D == 1) continue;
+            if (D == 1 && !(p->useRccl && p->selfMessages)) continue;
             size_t bytes = 0;
             if (bad(rtd_field_wait_plan(s.h, mine[(size_t)i], nullptr, &bytes))) break;   // the superposition is still running
             if (slot >= s.msgOut.size()) { s.msgOut.push_back(nullptr); s.msgOutCap.push_back(0); }
@@ -202,21 +253,22 @@ int rtd_plan_compute(rtd_plan_t p, const rtd_beam* beams, int n_beams, float* do
             if (bad(rtd_field_export_bev(s.h, mine[(size_t)i], s.msgOut[slot], s.msgOutCap[slot]))) break;
             msgBytes[(size_t)i] = bytes; msgPtr[(size_t)i] = s.msgOut[slot];
         }
-        if (s.status == RTD_OK && D > 1) bad(rtd_sync(s.h));          // the messages are complete before the others pull them
+        if (s.status == RTD_OK && (D > 1 || (p->useRccl && p->selfMessages))) bad(rtd_sync(s.h));   // the messages are complete before they travel
         s.ms[1] = (float)(nowMs() - t);
         bar.wait();
 
-        // ---- 3. pull the other devices' messages (peer copies over xGMI; same-device slots are read in place) ----
+        // ---- 3. exchange of the messages: peer copies over xGMI (same-device slots are read in place), or RCCL broadcasts ----
         t = nowMs();
         std::vector<const void*> slabOf((size_t)n_beams, nullptr);
         std::vector<rtd_field> theirs((size_t)n_beams, nullptr);
-        if (!anyFailed()) {
+        const bool viaMessage = p->useRccl && p->selfMessages;         // owners read the exchanged copy too
+        if (!anyFailed() && (D > 1 || viaMessage)) {
             size_t in = 0;
             for (int i = 0; i < n_beams && s.status == RTD_OK; ++i) {
                 const int owner = i % D;
-                if (owner == d) continue;
+                if (owner == d && !viaMessage && !p->useRccl) continue;
                 const DevSlot& o = p->dev[(size_t)owner];
-                if (o.device == s.device) { slabOf[(size_t)i] = msgPtr[(size_t)i]; continue; }
+                if (!p->useRccl && o.device == s.device) { slabOf[(size_t)i] = msgPtr[(size_t)i]; continue; }
                 if (in >= s.msgIn.size()) { s.msgIn.push_back(nullptr); s.msgInCap.push_back(0); }
                 if (msgBytes[(size_t)i] > s.msgInCap[in]) {
                     if (s.msgIn[in]) (void)rtd_device_free(s.h, s.msgIn[in]);
@@ -224,7 +276,12 @@ int rtd_plan_compute(rtd_plan_t p, const rtd_beam* beams, int n_beams, float* do
                     if (bad(rtd_device_alloc(s.h, msgBytes[(size_t)i], &s.msgIn[in]))) break;
                     s.msgInCap[in] = msgBytes[(size_t)i];
                 }
-                if (badHip(hipMemcpyPeerAsync(s.msgIn[in], s.device, msgPtr[(size_t)i], o.device, msgBytes[(size_t)i], s.copyStream))) break;
+                if (p->useRccl) {
+                    // every device makes the call for every beam, in beam order: root = the device that computed it
+                    const ncclResult_t r = p->rccl.broadcast(owner == d ? msgPtr[(size_t)i] : s.msgIn[in], s.msgIn[in], msgBytes[(size_t)i], ncclUint8, owner,
+                                                             p->comms[(size_t)d], s.copyStream);
+                    if (r != ncclSuccess) { if (s.status == RTD_OK) { s.status = RTD_ERR_HIP; s.error = std::string("RCCL: ") + p->rccl.errorString(r); failed[(size_t)d] = 1; } break; }
+                } else if (badHip(hipMemcpyPeerAsync(s.msgIn[in], s.device, msgPtr[(size_t)i], o.device, msgBytes[(size_t)i], s.copyStream))) break;
                 slabOf[(size_t)i] = s.msgIn[in];
                 ++in;
             }
@@ -236,7 +293,7 @@ int rtd_plan_compute(rtd_plan_t p, const rtd_beam* beams, int n_beams, float* do
         t = nowMs();
         if (!anyFailed() && slabN) {
             for (int i = 0; i < n_beams && s.status == RTD_OK; ++i) {
-                if (i % D == d) { bad(rtd_field_transfer(s.h, mine[(size_t)i], doseBase, clipLo, clipHi)); continue; }
+                if (i % D == d && !viaMessage) { bad(rtd_field_transfer(s.h, mine[(size_t)i], doseBase, clipLo, clipHi)); continue; }
                 if (bad(rtd_field_create_remote(s.h, &beams[i], dose_dims, &theirs[(size_t)i]))) break;
                 if (bad(rtd_field_attach_bev(s.h, theirs[(size_t)i], slabOf[(size_t)i]))) break;
                 bad(rtd_field_transfer(s.h, theirs[(size_t)i], doseBase, clipLo, clipHi));

@@ -230,3 +230,22 @@ def test_released_workspace_is_taken_over(engine, synth):
         eng.to_host(out, d)
         np.testing.assert_array_equal(out, want)
         eng.device_free(d)
+
+
+def test_in_process_plan_over_rccl_transport(orc, engine, synth, monkeypatch):
+    """RTD_PLAN_TRANSPORT=rccl: the slabs travel by ncclBroadcast on communicators made with ncclCommInitAll (librccl opened on demand).
+    One GPU allows one rank only; RTD_PLAN_SELF_MESSAGES makes the owner transfer from the broadcast copy, so export -> RCCL ->
+    attach -> transfer all run: same dose bits as the sequential call. Duplicate device ids are refused (one RCCL rank per GPU)."""
+    scn = _scn(synth, angles=(0.0, 90.0))
+    want = _sequential(engine, scn)
+    monkeypatch.setenv("RTD_PLAN_TRANSPORT", "rccl")
+    monkeypatch.setenv("RTD_PLAN_SELF_MESSAGES", "1")
+    dose = np.zeros_like(scn.ct)
+    with engine.Plan([0]) as plan:
+        plan.set_luts(scn.luts)
+        plan.set_ct(scn.ct)
+        _, pt = plan.compute(scn.beams, dose)
+        assert pt["exchange_ms"] > 0
+    np.testing.assert_array_equal(dose, want)
+    with pytest.raises(engine.RtdError):
+        engine.Plan([0, 0])
