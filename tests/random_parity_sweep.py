@@ -35,6 +35,8 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
             print("seed", seed, "ABOVE-FLOOR deviation:", str(e))
         elif "err[~mask]" in tb:               # tail voxels (< 1e-3 of max) beyond the tight floor tolerance: radius-class flip
             print("seed", seed, "TAIL-ONLY deviation (voxels below 1e-3 of the maximum)")
+        elif "tile_radius differs" in str(e):
+            print("seed", seed, "RADIUS-CLASS difference:", str(e)[:300])
         else:
             raise
     n_ok += 1
