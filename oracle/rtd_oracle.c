@@ -484,7 +484,8 @@ static void stage_trace(const float* ct, const int ctd[3], const rtd_luts* l, co
     }
 }
 
-/* Stage 2: gpuConvolution2D (gpu_convolution_2d.cu:16-71). rsqrtf(2.0f) is written 1/sqrtf(2). */
+/* Stage 2: gpuConvolution2D (gpu_convolution_2d.cu:16-71). rsqrtf(2.0f) is written 1/sqrtf(2); the device erff is
+ * rtd_erf_det (include/rtd_detmath.h), the same bits as the engine under test evaluates. */
 static void stage_conv2d(const float* in, float* interm, float* out, const f2* sigmas, const unsigned int inDims[3],
                          const unsigned int outDims[3], f3 spotDelta, f3 spotOffset, f3 rayDelta, f3 rayOffset,
                          f2 pxSpMult, float convCut) {
@@ -503,7 +504,7 @@ static void stage_conv2d(const float* in, float* interm, float* out, const f2* s
             float dist = (float)cur * inOutDeltaX + inOutOffsetX - (float)outIdxX;
             while (dist < (convCut * sigmaEff + 0.5f) && cur < inW) {
                 if (cur >= 0 && cur < inW)
-                    res += 0.5f * (erff((dist + 0.5f) * rSigmaEff) - erff((dist - 0.5f) * rSigmaEff))
+                    res += 0.5f * (rtd_erf_det((dist + 0.5f) * rSigmaEff) - rtd_erf_det((dist - 0.5f) * rSigmaEff))
                            * in[(size_t)z * inW * inH + (size_t)idxY * inW + cur];
                 ++cur;
                 dist = (float)cur * inOutDeltaX + inOutOffsetX - (float)outIdxX;
@@ -520,7 +521,7 @@ static void stage_conv2d(const float* in, float* interm, float* out, const f2* s
             float dist = (float)cur * inOutDeltaY + inOutOffsetY - (float)outIdxY;
             while (dist < (convCut * sigmaEff + 0.5f) && cur < inH) {
                 if (cur >= 0 && cur < inH)
-                    res += 0.5f * (erff((dist + 0.5f) * rSigmaEff) - erff((dist - 0.5f) * rSigmaEff))
+                    res += 0.5f * (rtd_erf_det((dist + 0.5f) * rSigmaEff) - rtd_erf_det((dist - 0.5f) * rSigmaEff))
                            * interm[(size_t)z * outW * inH + (size_t)cur * outW + idxX];
                 ++cur;
                 dist = (float)cur * inOutDeltaY + inOutOffsetY - (float)outIdxY;
@@ -661,6 +662,7 @@ static void stage_tile_radius(const float* rs, int W, int H, int first, int laye
 }
 
 float orc_pow_det(float x, float y) { return rtd_pow_det(x, y); }   /* for the known-answer test of the shared routine */
+float orc_erf_det(float x) { return rtd_erf_det(x); }
 
 /* Host batching of radii (kernel_wrapper.cu:966-976): effRad[rad] = template radius of the launch that
  * serves tiles of radius rad (kernel_wrapper.cuh:443-448). Returns layerMaxPrimSuperpR. */

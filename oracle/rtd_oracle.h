@@ -19,6 +19,7 @@ int orc_get_max_threads(void);
 void orc_footprint_start(size_t nVoxels);
 long long orc_footprint_stop(void);
 float orc_pow_det(float x, float y);
+float orc_erf_det(float x);
 
 /* host helpers (vector_find.h, vector_interpolate.h) */
 float orc_find_max(const float* list, int n);

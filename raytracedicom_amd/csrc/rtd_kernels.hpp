@@ -507,8 +507,12 @@ __global__ __launch_bounds__(1024) void k_plan(FieldState* st, LayerPlan* layers
     }
 }
 
+#define RTD_DM_FN __device__ inline
+#include "../../include/rtd_detmath.h"
+
 // ------------------------------------------------------------------------------------------------
-// K3/K4: spot -> ray weights, separable erf-integrated Gaussian resampling (gpu_convolution_2d.cu:16-59).
+// K3/K4: spot -> ray weights, separable erf-integrated Gaussian resampling (gpu_convolution_2d.cu:16-59). The error
+// function is rtd_erf_det (rtd_detmath.h): bit-reproducible, so the RAY_WEIGHT_CUTOFF liveness test downstream is too.
 __global__ void k_conv_x(const float* __restrict__ in, float* __restrict__ out, const LayerPlan* __restrict__ layers,
                          const FieldState* __restrict__ st, FieldConst fc) {
     const int idxY = blockDim.y * blockIdx.y + threadIdx.y;
@@ -528,7 +532,7 @@ __global__ void k_conv_x(const float* __restrict__ in, float* __restrict__ out, 
         float dist = (float)cur * inOutDelta + inOutOffset - (float)outIdxX;
         while (dist < (cut * sigmaEff + 0.5f) && cur < inWidth) {
             if (cur >= 0 && cur < inWidth)
-                res += 0.5f * (erff((dist + 0.5f) * rSigmaEff) - erff((dist - 0.5f) * rSigmaEff))
+                res += 0.5f * (rtd_erf_det((dist + 0.5f) * rSigmaEff) - rtd_erf_det((dist - 0.5f) * rSigmaEff))
                        * in[(size_t)z * inWidth * height + (size_t)idxY * inWidth + cur];
             ++cur;
             dist = (float)cur * inOutDelta + inOutOffset - (float)outIdxX;
@@ -555,7 +559,7 @@ __global__ void k_conv_y(const float* __restrict__ in, float* __restrict__ out, 
         float dist = (float)cur * inOutDelta + inOutOffset - (float)outIdxY;
         while (dist < (cut * sigmaEff + 0.5f) && cur < inHeight) {
             if (cur >= 0 && cur < inHeight)
-                res += 0.5f * (erff((dist + 0.5f) * rSigmaEff) - erff((dist - 0.5f) * rSigmaEff))
+                res += 0.5f * (rtd_erf_det((dist + 0.5f) * rSigmaEff) - rtd_erf_det((dist - 0.5f) * rSigmaEff))
                        * in[(size_t)z * width * inHeight + (size_t)cur * width + idxX];
             ++cur;
             dist = (float)cur * inOutDelta + inOutOffset - (float)outIdxY;
@@ -586,8 +590,6 @@ __global__ void k_conv_y(const float* __restrict__ in, float* __restrict__ out, 
 // does not come from those values: x -> step/(sqrt2*(sqrt(x)+delta)) is monotone under correct rounding, so the tile
 // minimum of the exact 1/sigma equals that function of the tile MAXIMUM of sigmaSq, evaluated once per (step, tile) with
 // IEEE sqrt and division.
-#define RTD_DM_FN __device__ inline
-#include "../../include/rtd_detmath.h"
 
 constexpr int kFillBatch = 8;   // steps per batch: inputs fetched one batch ahead, one block barrier per batch
 

@@ -1,6 +1,7 @@
 """Random parity sweep on a GPU box (not collected by pytest): seeded random scenarios through tests/test_gpu_parity._compare_field,
 every intermediate and the dose against the CPU oracle. Usage: python tests/random_parity_sweep.py FIRST_SEED END_SEED.
-Deviations that are float-threshold flips are reported and the sweep goes on; anything else raises."""
+Ray weights and every integer are compared bit for bit; dose deviations confined to the tail are reported and the sweep goes on;
+anything else raises."""
 import os, sys, math
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -29,8 +30,6 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         tb = traceback.format_exc()
         if "(1.0, 0, 0.0)" in str(e):          # pencil too thin for the gamma sampling grid: every other comparison passed
             print("seed", seed, "gamma had no voxels to evaluate (all other comparisons passed)")
-        elif "Arrays are not equal" in str(e) and "first_passive" in tb and "Mismatched elements: 1 /" in str(e):
-            print("seed", seed, "RAY-WEIGHT cut-off flip on one ray")
         elif "max rel err" in str(e):
             print("seed", seed, "ABOVE-FLOOR deviation:", str(e))
         elif "err[~mask]" in tb:               # tail voxels (< 1e-3 of max) beyond the tight floor tolerance: radius-class flip

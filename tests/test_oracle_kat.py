@@ -221,3 +221,24 @@ def test_deterministic_power_matches_a_double_precision_pow(orc):
     got = np.array([L.orc_pow_det(float(x), float(y)) for x in xs], dtype=np.float64)
     ref = np.power(xs.astype(np.float64), np.float64(y))
     assert (np.abs(got - ref) / ref).max() < 2.7e-7
+
+
+def test_deterministic_erf_matches_scipy(orc):
+    """rtd_erf_det (include/rtd_detmath.h) stands in for the device erff of the spot->ray convolution (gpu_convolution_2d.cu:27,51) in
+    the oracle's GPU-convolution stage AND in the engine, so the RAY_WEIGHT_CUTOFF liveness of every ray is the same bits on both.
+    Pinned against scipy's double-precision erf: <= 1e-7 absolute everywhere, <= 8e-8 relative below the branch point; odd; saturates."""
+    import ctypes as C
+    from scipy import special
+    L = orc.lib()
+    L.orc_erf_det.restype = C.c_float
+    L.orc_erf_det.argtypes = [C.c_float]
+    rng = np.random.default_rng(6)
+    xs = np.concatenate([rng.uniform(-4.5, 4.5, 30000), rng.uniform(-1e-3, 1e-3, 2000),
+                         [0.0, 0.875, -0.875, 0.87499994, 0.8750001, 3.9999998, 4.0, -4.0, 7.0, 1e-20, -1e-20]]).astype(np.float32)
+    got = np.array([L.orc_erf_det(float(x)) for x in xs], dtype=np.float64)
+    ref = special.erf(xs.astype(np.float64))
+    assert np.abs(got - ref).max() <= 1.0e-7
+    small = (np.abs(xs) < 0.875) & (xs != 0)
+    assert (np.abs(got - ref)[small] / np.abs(ref[small])).max() <= 8e-8
+    assert L.orc_erf_det(0.0) == 0.0 and L.orc_erf_det(4.0) == 1.0 and L.orc_erf_det(-7.0) == -1.0
+    np.testing.assert_array_equal(got, -np.array([L.orc_erf_det(float(-x)) for x in xs]))
