@@ -142,9 +142,23 @@ def main():
     ex = None
     if world > 1:
         remote = {r: eng.create_field(scn.beams[r], scn.dims, remote=True) for r in range(world) if r != rank}
-        ex = plan.BevExchange(dist, rank, world, remote, scn.dims, new_bytes=lambda k: torch.empty(int(k), dtype=torch.uint8, device=dev))
+        ex = plan.BevExchange(dist, rank, world, remote, scn.dims, new_bytes=lambda k: torch.empty(int(k), dtype=torch.uint8, device=dev),
+                               zero_box=lambda b, lo, hi: doses[b][lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1].zero_(),
+                               transfer_all=lambda fs, d, lo, hi: eng.transfer_fields_init(fs, d, lo, hi))
+        # This rank's field measured alone (best of 8 runs after 3 warm-ups): time up to its BEV dose and transfer cost per box
+        # voxel. The slabs are then cut so that the ranks' step times come out even — fields differ in cost
+        # (profiles/r02_angles.json) and a rank with an expensive field gets a thinner slab; the dose does not depend on the cut.
+        head_us, ps_kvox = [], []
+        for j in range(11):
+            fld.compute_bev()
+            fld.transfer(doses[0].data_ptr())
+            t_j, _ = fld.finish()
+            if j >= 3 and t_j.get("transfer_voxels", 0) > 0:
+                head_us.append(1000.0 * (t_j["total_ms"] - t_j["transforming_ms"]))
+                ps_kvox.append(1.25 * t_j["transforming_ms"] * 1e9 / t_j["transfer_voxels"] * 1000.0)   # + 25 %: the clear of the box
+        doses[0].zero_()
         fld.compute_bev()
-        ex.setup(fld)               # message capacity, dose boxes, slab partition: the fields keep their geometry
+        ex.setup(fld, head_us=min(head_us) if head_us else None, transfer_ps_per_kvoxel=min(ps_kvox) if ps_kvox else None)   # message capacity, dose boxes, slab partition: the fields keep their geometry
         fld.finish()
     main_stream.synchronize()
     step_no = [0]
@@ -360,8 +374,9 @@ def main():
                        "ct_footprint_voxels": ct_fp,
                        "exchange": ("none" if world == 1 else
                                     "one RCCL all-gather of the packed BEV slabs per plan (%d x %.1f MB), overlapped with the next plan's kernels; every "
-                                    "rank transfers every field, in field order, into its slab of the dose volume (axis %d, ranges %s): the volume stays "
-                                    "sharded by slabs, no dose data crosses xGMI" % (world, ex.cap / 1e6, ex.axis, ex.ranges))},
+                                    "rank writes its slab of the dose volume (axis %d, ranges %s) with all fields, in field order, in one fused launch: the volume stays "
+                                    "sharded by slabs, no dose data crosses xGMI; slabs cut for even step times from the ranks' measured field times %s us and "
+                                    "transfer rates %s ps per 1000 voxels" % (world, ex.cap / 1e6, ex.axis, ex.ranges, ex.heads_us, ex.rates_ps_kvox))},
             "ms_plan": round(ms_per_step, 4),
             "ms_plan_latency": round(ms_latency, 4),
             "throughput_3_streams": multi,

@@ -244,6 +244,15 @@ int rtd_field_transfer(rtd_handle h, rtd_field f, float* dev_dose, const int32_t
  * field's dose box (e.g. the volume the same field was transferred into by the previous plan): the box is written — dose
  * or zero — instead of accumulated into, which replaces rtd_field_clear_dose + the read half of the read-modify-write. */
 int rtd_field_transfer_init(rtd_handle h, rtd_field f, float* dev_dose, const int32_t clip_min[3], const int32_t clip_max[3]);
+/* Several fields — own BEV doses and / or attached slabs — into ONE box of the dose grid in one launch: every voxel of the
+ * inclusive box [box_min, box_max] (NULL = the whole grid) is WRITTEN with 0 + field 0 + field 1 + ..., the positive samples
+ * in list order: bit for bit what rtd_field_transfer of each field in turn accumulates into a zeroed box (the beam loop of
+ * kernel_wrapper.cu:601 with its primTransfDiv launches, :1216), without the read-modify-write passes and without a clear.
+ * Voxels outside the box are not touched: a GPU of a multi-GPU plan passes its slab of the volume, cut to the bounding box of
+ * the fields' dose boxes. At most 16 fields; not with nuclear_corr. rtd_field_finish of the LAST own field of the list (the
+ * first field if all are remote) waits for the launch and reports its duration as transforming_ms. */
+int rtd_fields_transfer_init(rtd_handle h, const rtd_field* fields, uint32_t n_fields, float* dev_dose, const int32_t box_min[3],
+                             const int32_t box_max[3]);
 int rtd_field_wait_plan(rtd_handle h, rtd_field f, rtd_field_info* info, size_t* packed_bytes);
 size_t rtd_bev_message_bound(rtd_handle h, rtd_field f);
 int rtd_field_export_bev(rtd_handle h, rtd_field f, void* dev_buf, size_t capacity);

@@ -1625,6 +1625,123 @@ __global__ __launch_bounds__(256) void k_transfer_t(float* __restrict__ dose, in
     }
 }
 
+// Several fields into one box in ONE pass (rtd_fields_transfer_init): every voxel of `box` is WRITTEN with
+// ((0 + field 0) + field 1) + ... — the positive samples in list order, exactly the values that rtd_field_transfer of each field in
+// turn would have accumulated into a zeroed volume (same samples, same order of the float additions), without the N - 1
+// read-modify-write passes over the volume, without a clear, in one launch. What a GPU of a multi-GPU plan does with the BEV slabs
+// it gathered (its slab of the volume = box), and why it exists: N clipped launches per plan step measured 2x the per-voxel
+// cost of one full launch.
+// Block = one 16^3 brick; thread (x, y) of the brick keeps its 16 z sums in a private LDS column (registers would have to be
+// indexed dynamically by the rolled chunk loops). A field is sampled with the lanes along the dose axis that moves fastest along its
+// BEV x (its transferMode, as k_transfer / k_transfer_t): mode 0 directly, modes 1 / 2 through an LDS tile that turns the
+// gather layout into the (x, y) layout of the sums.
+constexpr int kMultiMaxFields = 16;
+struct MultiFields {
+    const float* bev[kMultiMaxFields];
+    const FieldState* st[kMultiMaxFields];
+    int mode[kMultiMaxFields];
+    int n;
+};
+
+__global__ __launch_bounds__(256, 6) void k_transfer_multi(float* __restrict__ dose, int nx, int ny, int nz, MultiFields mf, ClipBox box) {
+    __shared__ float accT[16][256];                                   // [z][thread]: a thread's 16 sums (private column: no barriers needed)
+    __shared__ float tile[4][16][17];
+    const int nbx = (box.hi[0] - box.lo[0]) / 16 + 1, nby = (box.hi[1] - box.lo[1]) / 16 + 1, nbz = (box.hi[2] - box.lo[2]) / 16 + 1;
+    const int nBricks = nbx * nby * nbz;
+    const int tid = threadIdx.x;
+    const int aX = tid & 15, aY = tid >> 4;                           // layout of the sums: lanes along x
+    const int gB = tid & 15, gX = tid >> 4;                           // layout of the gathers of modes 1 / 2: lanes along B
+    const size_t nxy = (size_t)nx * ny;
+    for (int brick = blockIdx.x; brick < nBricks; brick += gridDim.x) {
+        const int x0 = box.lo[0] + 16 * (brick % nbx), y0 = box.lo[1] + 16 * ((brick / nbx) % nby), z0 = box.lo[2] + 16 * (brick / (nbx * nby));
+#pragma unroll
+        for (int z = 0; z < 16; ++z) accT[z][tid] = 0.0f;
+        for (int fi = 0; fi < mf.n; ++fi) {
+            const FieldState* st = mf.st[fi];
+            const int first = st->beamFirstInside;
+            const int slabZ = st->firstCalculatedPassive - first;
+            if (slabZ <= 0 || st->errorFlags) continue;               // (uniform) as k_transfer: such a field deposits nothing
+            // the field's own dose box: voxels outside it are not visited by its transfer
+            // (cut to the written box: the voxels of a partial brick beyond it are neither sampled nor written)
+            const int bx0 = st->tboxMin[0], by0 = st->tboxMin[1], bz0 = st->tboxMin[2];
+            const int bx1 = min(st->tboxMax[0], box.hi[0]), by1 = min(st->tboxMax[1], box.hi[1]), bz1 = min(st->tboxMax[2], box.hi[2]);
+            if (x0 > bx1 || x0 + 15 < bx0 || y0 > by1 || y0 + 15 < by0 || z0 > bz1 || z0 + 15 < bz0) continue;   // (uniform)
+            const TransferParams p0 = st->transfer;
+            const int pW = st->packW, pH = st->packH;
+            const float pX0 = (float)st->packX0, pY0 = (float)st->packY0;
+            const float* slab = mf.bev[fi] + (size_t)st->slabFirst * pW * pH;
+            const float exLo = (float)(st->bevLo[0] - 1), exHi = (float)(st->bevHi[0] + 1), eyLo = (float)(st->bevLo[1] - 1), eyHi = (float)(st->bevHi[1] + 1);
+            auto sampleAt = [&](const Vec3& pos) -> float {
+                if (pos.x > exLo && pos.x < exHi && pos.y > eyLo && pos.y < eyHi)
+                    return sample3dBorder(slab, pW, pH, slabZ, pos.x - pX0, pos.y - pY0, pos.z);
+                return 0.0f;
+            };
+            const int mode = mf.mode[fi];
+            if (mode == 0) {
+                const int x = x0 + aX, y = y0 + aY;
+                const bool in = x >= bx0 && x <= bx1 && y >= by0 && y <= by1;
+                TransferParams p = p0;
+                p.init(x, y);
+#pragma unroll 1
+                for (int c = 0; c < 16; c += 4) {
+                    float v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int z = z0 + c + u;
+                        v[u] = (in && z >= bz0 && z <= bz1) ? sampleAt(p.getFanIdx(z)) : 0.0f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) if (v[u] > 0.0f) accT[c + u][tid] += v[u];
+                }
+            } else if (mode == 1) {
+                // lanes along y, z walked: tile[u][y][x]
+                const int x = x0 + gX, y = y0 + gB;
+                const bool in = x >= bx0 && x <= bx1 && y >= by0 && y <= by1;
+                TransferParams p = p0;
+                p.init(x, y);
+#pragma unroll 1
+                for (int c = 0; c < 16; c += 4) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int z = z0 + c + u;
+                        tile[u][gB][gX] = (in && z >= bz0 && z <= bz1) ? sampleAt(p.getFanIdx(z)) : 0.0f;
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const float v = tile[u][aY][aX]; if (v > 0.0f) accT[c + u][tid] += v; }
+                    __syncthreads();
+                }
+            } else {
+                // lanes along z, y walked: tile[u][z][x]; the wave that owns rows c .. c+3 of the brick collects a chunk
+                const int x = x0 + gX, z = z0 + gB;
+                const bool in = x >= bx0 && x <= bx1 && z >= bz0 && z <= bz1;
+#pragma unroll 1
+                for (int c = 0; c < 16; c += 4) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int y = y0 + c + u;
+                        float v = 0.0f;
+                        if (in && y >= by0 && y <= by1) { TransferParams q = p0; q.init(x, y); v = sampleAt(q.getFanIdx(z)); }
+                        tile[u][gB][gX] = v;
+                    }
+                    __syncthreads();
+                    if ((aY >> 2) == (c >> 2)) {
+#pragma unroll
+                        for (int zz = 0; zz < 16; ++zz) { const float v = tile[aY & 3][zz][aX]; if (v > 0.0f) accT[zz][tid] += v; }
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        const int x = x0 + aX, y = y0 + aY;
+        if (x <= box.hi[0] && y <= box.hi[1]) {
+            float* res = dose + (size_t)z0 * nxy + (size_t)y * nx + x;
+#pragma unroll
+            for (int z = 0; z < 16; ++z) if (z0 + z <= box.hi[2]) res[z * nxy] = accT[z][tid];
+        }
+    }
+}
+
 // Zeroes the bricks of the dose box of the last transfer (rtd_field_clear_dose): same brick walk as k_transfer.
 __global__ __launch_bounds__(256) void k_clear_box(float* __restrict__ dose, int nx, int ny, const FieldState* __restrict__ st, int zChunk,
                                                     ClipBox clip) {

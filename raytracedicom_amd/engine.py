@@ -67,6 +67,7 @@ def lib():
         L.rtd_field_compute_bev.argtypes = [vp, vp]
         L.rtd_field_transfer.argtypes = [vp, vp, vp, i3, i3]
         L.rtd_field_transfer_init.argtypes = [vp, vp, vp, i3, i3]
+        L.rtd_fields_transfer_init.argtypes = [vp, C.POINTER(C.c_void_p), C.c_uint32, vp, i3, i3]
         L.rtd_field_wait_plan.argtypes = [vp, vp, C.POINTER(abi.RtdFieldInfo), C.POINTER(C.c_size_t)]
         L.rtd_bev_message_bound.argtypes = [vp, vp]
         L.rtd_bev_message_bound.restype = C.c_size_t
@@ -249,6 +250,13 @@ class Engine:
 
     def create_field(self, beam, dose_dims, remote=False):
         return Field(self, beam, dose_dims, remote=remote)
+
+    def transfer_fields_init(self, fields, dev_dose, box_min=None, box_max=None):
+        """rtd_fields_transfer_init: every voxel of the inclusive dose-index box is written with 0 + fields[0] + fields[1] + ...
+        in one launch (bit for bit the loop of Field.transfer over the fields into a zeroed box); asynchronous."""
+        arr = (C.c_void_p * len(fields))(*[f._h for f in fields])
+        lo, hi = Field._clip(box_min, box_max)
+        self._check(lib().rtd_fields_transfer_init(self._h, arr, len(fields), C.c_void_p(int(dev_dose)), lo, hi))
 
     # device buffers owned by the handle
     def device_alloc(self, nbytes):

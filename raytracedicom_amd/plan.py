@@ -472,11 +472,35 @@ class PipelinedSlabReduce(PipelinedBoxReduce):
 # The plan's dose volume is left sharded by slabs across the GPUs (each rank copies its slab to the host over its own PCIe
 # link); no dose data crosses between GPUs, and the result is bit-identical to the one-GPU loop.
 
-def balanced_slabs(boxes, dims, world):
+def _water_fill(head, total, per_unit):
+    """Shares s_r >= 0 with sum s_r = total and head_r + per_unit * s_r equal for every rank that gets a share (ranks whose head
+    already exceeds that level get none)."""
+    n = len(head)
+    if total <= 0 or per_unit <= 0:
+        return [total / n] * n
+    order = sorted(range(n), key=lambda r: head[r])
+    level = None
+    for m in range(1, n + 1):                                        # the m ranks with the smallest heads share the work
+        lv = (sum(head[order[j]] for j in range(m)) + per_unit * total) / m
+        if m == n or lv <= head[order[m]]:
+            level = lv
+            break
+    return [max(0.0, (level - head[r]) / per_unit) for r in range(n)]
+
+
+def balanced_slabs(boxes, dims, world, head=None, per_voxel=None):
     """Slabs for BevExchange: the dose grid is cut into `world` slabs along one axis so that the transfer work — for every slab
     the voxels of ALL fields' dose boxes inside it — is as even as it can be. boxes: 6-int inclusive boxes (x0, y0, z0, x1, y1, z1),
-    an empty box has max < min. Returns (axis, [(lo, hi) inclusive index range per rank along that axis]); slabs tile [0, dims[axis])."""
+    an empty box has max < min. Returns (axis, [(lo, hi) inclusive index range per rank along that axis]); slabs tile [0, dims[axis]).
+
+    A box may carry a 7th entry, the relative cost per voxel of transferring that field (oblique beams have large, mostly empty
+    boxes that cost less per voxel); the load of a slab is then the cost-weighted voxel count.
+    head[r] (time rank r spends on its own field before it transfers, any unit) and per_voxel (time per unit of load, same
+    unit) make the cut uneven on purpose: fields differ in cost (an oblique beam's superposition took 0.55 ms against 0.47 ms,
+    profiles/r02_angles.json), so a rank with an expensive field gets a thinner slab and head[r] + per_voxel * load(slab r) — the
+    rank's step time — is what is evened out. The dose does not depend on the cut (every voxel receives every field in field order)."""
     valid = [b for b in boxes if all(b[3 + a] >= b[a] for a in range(3))]
+    weighted = head is not None and per_voxel is not None and per_voxel > 0
     best = None
     for axis in (2, 1, 0):                                            # ties: z first (contiguous slabs of the [z][y][x] volume)
         n = int(dims[axis])
@@ -486,6 +510,7 @@ def balanced_slabs(boxes, dims, world):
             for a in range(3):
                 if a != axis:
                     area *= b[3 + a] - b[a] + 1
+            area *= b[6] if len(b) > 6 else 1                         # the field's own cost per voxel, if given
             prof[max(b[axis], 0)] += area
             prof[min(b[3 + axis], n - 1) + 1] -= area
         load, run = [], 0
@@ -493,18 +518,25 @@ def balanced_slabs(boxes, dims, world):
             run += prof[i]
             load.append(run)
         total = sum(load)
+        shares = _water_fill([float(h) for h in head], float(total), float(per_voxel)) if weighted else [total / world] * world
+        target, run_t = [], 0.0                                       # cumulative share in front of slab r
+        for r in range(world):
+            target.append(run_t)
+            run_t += shares[r]
         cuts, acc, r = [0], 0, 1
         for i in range(n):
             acc += load[i]
-            while r < world and acc * world >= total * r and len(cuts) < world:
+            while r < world and acc >= target[r] and len(cuts) < world:
                 cuts.append(i + 1)
                 r += 1
         while len(cuts) < world:
             cuts.append(n)
         cuts.append(n)
         ranges = [(cuts[k], cuts[k + 1] - 1) for k in range(world)]
-        worst = max((sum(load[a:b + 1]) for a, b in ranges if b >= a), default=0)
-        if best is None or worst < best[0]:
+        cost = [(float(head[k]) if weighted else 0.0) + (float(per_voxel) if weighted else 1.0) * (sum(load[a:b + 1]) if b >= a else 0)
+                for k, (a, b) in enumerate(ranges)]
+        worst = max(cost, default=0)
+        if best is None or worst < 0.97 * best[0]:                   # z unless another axis is clearly better (contiguous slabs)
             best = (worst, axis, ranges)
     return best[1], best[2]
 
@@ -517,28 +549,45 @@ class BevExchange:
     export_bev, attach_bev, transfer, clear_dose_box) — the CPU tests drive this class with numpy stand-ins over gloo.
     All device work is issued on the CURRENT torch stream, which must be the stream the engine launches on."""
 
-    def __init__(self, dist, rank, world, remote_fields, dims, new_bytes, data_ptr=lambda t: t.data_ptr(), n_buffers=2):
+    def __init__(self, dist, rank, world, remote_fields, dims, new_bytes, data_ptr=lambda t: t.data_ptr(), n_buffers=2, zero_box=None,
+                 transfer_all=None):
         self.dist, self.rank, self.world, self.dims = dist, rank, world, tuple(int(d) for d in dims)
         self.remote = remote_fields            # dict rank -> remote field object
         self.new_bytes, self.data_ptr = new_bytes, data_ptr
         self.n_buffers = n_buffers
+        self.zero_box = zero_box               # optional zero_box(b, lo, hi): zero an inclusive index box of dose volume b in ONE launch
+        # optional transfer_all(fields in rank order, dose_ptr, lo, hi): WRITE the box with 0 + field 0 + field 1 + ... in one launch
+        # (rtd_fields_transfer_init): replaces the per-field transfers AND the clear (the box is rewritten by every plan)
+        self.transfer_all = transfer_all
+        self.heads_us, self.rates_ps_kvox = None, None
         self.cap = None
         self.send, self.recv, self.work = [], [], []
         self.boxes = None
         self.axis, self.ranges = None, None
 
-    def setup(self, own_field):
-        """After the first compute_bev of the own field: message capacity (max over ranks), dose boxes, slab partition."""
+    def setup(self, own_field, head_us=None, transfer_ps_per_kvoxel=None):
+        """After the first compute_bev of the own field: message capacity (max over ranks), dose boxes, slab partition.
+        head_us: measured time of this rank's field up to its BEV dose; transfer_ps_per_kvoxel: measured cost of this rank's
+        transfer (+ clear) in picoseconds per 1000 box voxels (both optional, integers after rounding): when every rank supplies them the slabs are cut
+        so that the ranks' step times come out even (balanced_slabs), otherwise so that the transfer work does."""
         import torch
         info, nbytes = own_field.wait_plan()
         dev = self.new_bytes(1).device
-        mine = torch.tensor([int(nbytes)] + [int(v) for v in info["dose_box_min"]] + [int(v) for v in info["dose_box_max"]], dtype=torch.int64, device=dev)
+        have = head_us is not None and transfer_ps_per_kvoxel is not None
+        mine = torch.tensor([int(nbytes)] + [int(v) for v in info["dose_box_min"]] + [int(v) for v in info["dose_box_max"]]
+                            + [int(round(head_us)) if have else -1, int(round(transfer_ps_per_kvoxel)) if have else -1], dtype=torch.int64, device=dev)
         allv = [torch.empty_like(mine) for _ in range(self.world)]
         self.dist.all_gather(allv, mine)
         rows = torch.stack(allv).cpu().tolist()
         self.cap = (max(int(r[0]) for r in rows) + 255) // 256 * 256
         self.boxes = [[int(v) for v in r[1:7]] for r in rows]
-        self.axis, self.ranges = balanced_slabs(self.boxes, self.dims, self.world)
+        heads, rates = [int(r[7]) for r in rows], [int(r[8]) for r in rows]
+        self.heads_us, self.rates_ps_kvox = heads, rates
+        if min(heads) >= 0 and min(rates) > 0:                       # every rank measured: even out the step times
+            weighted = [bx + [rates[r]] for r, bx in enumerate(self.boxes)]      # load in ps per 1000 voxels x voxels
+            self.axis, self.ranges = balanced_slabs(weighted, self.dims, self.world, head=heads, per_voxel=1e-9)   # -> us
+        else:
+            self.axis, self.ranges = balanced_slabs(self.boxes, self.dims, self.world)
         self.send = [self.new_bytes(self.cap) for _ in range(self.n_buffers)]
         self.recv = [self.new_bytes(self.cap * self.world) for _ in range(self.n_buffers)]
         self.work = [None] * self.n_buffers
@@ -564,6 +613,19 @@ class BevExchange:
         if hi[self.axis] < lo[self.axis]:
             return
         base = self.data_ptr(self.recv[b])
+        if self.transfer_all is not None:
+            box = self._union_box(lo, hi)
+            if box is None:
+                return
+            fields = []
+            for r in range(self.world):
+                if r == self.rank:
+                    fields.append(own_field)
+                else:
+                    self.remote[r].attach_bev(base + r * self.cap)
+                    fields.append(self.remote[r])
+            self.transfer_all(fields, dose_ptr, box[0], box[1])
+            return
         for r in range(self.world):
             if r == self.rank:
                 own_field.transfer(dose_ptr, lo, hi)
@@ -572,10 +634,26 @@ class BevExchange:
                 f.attach_bev(base + r * self.cap)
                 f.transfer(dose_ptr, lo, hi)
 
+    def _union_box(self, lo, hi):
+        """Bounding box of all fields' dose boxes inside [lo, hi], or None."""
+        valid = [bx for bx in self.boxes if all(bx[3 + a] >= bx[a] for a in range(3))]
+        if not valid:
+            return None
+        ulo = [max(lo[a], min(bx[a] for bx in valid)) for a in range(3)]
+        uhi = [min(hi[a], max(bx[3 + a] for bx in valid)) for a in range(3)]
+        return (ulo, uhi) if all(uhi[a] >= ulo[a] for a in range(3)) else None
+
     def clear(self, own_field, b, dose_ptr):
         """Zero what complete(own_field, b, dose_ptr) wrote (the fields' dose boxes inside this rank's slab)."""
         lo, hi = self.clip()
         if hi[self.axis] < lo[self.axis]:
+            return
+        if self.transfer_all is not None:                             # the fused transfer rewrites its whole box: nothing to clear
+            return
+        if self.zero_box is not None:                                 # one launch: the bounding box of all fields' boxes, inside the slab
+            box = self._union_box(lo, hi)
+            if box is not None:
+                self.zero_box(b, box[0], box[1])
             return
         base = self.data_ptr(self.recv[b])
         for r in range(self.world):

@@ -30,6 +30,29 @@ def test_balanced_slabs():
                     v += (a1 - a0 + 1) * np.prod([b[3 + a] - b[a] + 1 for a in range(3) if a != axis])
             load.append(v)
         assert max(load) <= 1.15 * sum(load) / world + 1
+    # cost-weighted cut: head[r] = time of rank r's own field, per_voxel = transfer cost; the ranks' step times come out even, the
+    # rank with the expensive field gets the thinner slab, a rank slower than the common level gets nothing
+    def loads(axis, ranges):
+        out = []
+        for lo, hi in ranges:
+            v = 0
+            for b in boxes:
+                a0, a1 = max(b[axis], lo), min(b[3 + axis], hi)
+                if a1 >= a0:
+                    v += (a1 - a0 + 1) * int(np.prod([b[3 + a] - b[a] + 1 for a in range(3) if a != axis]))
+            out.append(v)
+        return out
+    head, c = [744.0, 846.0, 720.0, 745.0], 4.5e-6
+    axis, ranges = plan.balanced_slabs(boxes, (512, 512, 512), 4, head=head, per_voxel=c)
+    assert ranges[0][0] == 0 and ranges[-1][1] == 511 and all(ranges[i][1] + 1 == ranges[i + 1][0] for i in range(3))
+    step = [h + c * v for h, v in zip(head, loads(axis, ranges))]
+    axis_e, ranges_e = plan.balanced_slabs(boxes, (512, 512, 512), 4)
+    step_e = [h + c * v for h, v in zip(head, loads(axis_e, ranges_e))]
+    assert max(step) - min(step) < 12.0 and max(step) < max(step_e) - 40.0     # (a plane of the busiest region costs ~ 5 us)
+    assert loads(axis, ranges)[1] == min(loads(axis, ranges))
+    axis, ranges = plan.balanced_slabs(boxes, (512, 512, 512), 4, head=[744.0, 5000.0, 720.0, 745.0], per_voxel=c)
+    assert ranges[1][1] < ranges[1][0] and ranges[-1][1] == 511                  # empty slab for the rank that is late anyway
+    assert plan.balanced_slabs(boxes, (512, 512, 512), 4, head=[7.0] * 4, per_voxel=c) == (axis_e, ranges_e)
     # degenerate inputs: no box at all, more ranks than planes
     axis, ranges = plan.balanced_slabs([[1, 1, 1, 0, 0, 0]], (8, 8, 8), 3)
     assert len(ranges) == 3 and ranges[-1][1] == 7
@@ -112,7 +135,8 @@ def _worker(rank, world, port, out_dir):
     own = _StandInField(scn.dims, mine, box)
     remote = {r: _StandInField(scn.dims) for r in range(world) if r != rank}
     ex = plan.BevExchange(dist, rank, world, remote, scn.dims, new_bytes=lambda k: torch.empty(int(k), dtype=torch.uint8))
-    ex.setup(own)
+    # measured costs (bench.py supplies them): rank 1 pretends to own an expensive field -> thinner slab, same dose
+    ex.setup(own, head_us=700 + 300 * (rank == 1), transfer_ps_per_kvoxel=4000)
     assert ex.cap % 256 == 0 and len(ex.ranges) == world
     vols = [torch.zeros((n, n, n), dtype=torch.float32) for _ in range(2)]
     # three pipelined plans on two alternating volumes / buffers (bench.py's loop): post plan i, then complete plan i - 1

@@ -145,6 +145,74 @@ def test_exported_bev_slab_transfers_identically_on_another_handle(engine, synth
         a.close(); b.close()
 
 
+@pytest.mark.parametrize("dist", [(math.inf, math.inf), (1800.0, 2200.0)])
+def test_fused_transfer_of_several_fields_equals_the_sequence(engine, synth, dist):
+    """rtd_fields_transfer_init: own fields and attached slabs at angles that take all three gather layouts (lanes along x, y, z)
+    written into a box in ONE launch == the loop of rtd_field_transfer over the same fields into a zeroed volume, bit for bit;
+    stale values inside the box are overwritten, voxels outside the box are not touched; the box need not be brick-aligned."""
+    angles = (0.0, 90.0, 37.0, 180.0, 270.0, 141.0)
+    scn = _scn(synth, angles=angles, dist=dist)
+    n = scn.n_voxels
+    nx, ny, nz = scn.dims
+    with engine.Engine(0) as eng:
+        eng.set_luts(scn.luts)
+        eng.set_ct(scn.ct)
+        own = [eng.create_field(b, scn.dims) for b in scn.beams]
+        want_d, got_d = eng.device_alloc(4 * n), eng.device_alloc(4 * n)
+        eng.device_zero(want_d, 4 * n)
+        msgs, fields = [], []
+        for i, f in enumerate(own):
+            f.compute_bev()
+            f.transfer(want_d)                                        # the sequence: field 0, 1, 2, ... accumulated
+            if i % 2:                                                 # every other field goes through the message path
+                info, nbytes = f.wait_plan()
+                m = eng.device_alloc(nbytes)
+                f.export_bev(m, nbytes)
+                r = eng.create_field(scn.beams[i], scn.dims, remote=True)
+                r.attach_bev(m)
+                msgs.append(m); fields.append(r)
+            else:
+                fields.append(f)
+            f.finish()
+        want = np.empty_like(scn.ct)
+        eng.to_host(want, want_d)
+        assert want.max() > 0
+        # (a) the whole grid
+        stale = np.full_like(scn.ct, 3.25)
+        eng.to_device(got_d, stale)
+        eng.transfer_fields_init(fields, got_d)
+        t, _ = own[4].finish()                                        # the last own field of the list carries the launch's events
+        assert t["total_ms"] > 0
+        got = np.empty_like(scn.ct)
+        eng.to_host(got, got_d)
+        np.testing.assert_array_equal(got, want)
+        # (b) an unaligned box: inside = the sequence, outside untouched
+        lo, hi = (5, 9, 33), (nx - 7, ny - 20, 77)
+        eng.to_device(got_d, stale)
+        eng.transfer_fields_init(fields, got_d, lo, hi)
+        own[4].finish()
+        eng.to_host(got, got_d)
+        inside = np.zeros(scn.ct.shape, dtype=bool)
+        inside[lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1] = True
+        np.testing.assert_array_equal(got[inside], want[inside])
+        assert (got[~inside] == 3.25).all()
+        # (c) slabs along z written one by one tile the volume
+        eng.to_device(got_d, stale)
+        cuts = [0, 40, 41, 90, nz]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            eng.transfer_fields_init(fields, got_d, (0, 0, a), (nx - 1, ny - 1, b - 1))
+        own[4].finish()
+        eng.to_host(got, got_d)
+        np.testing.assert_array_equal(got, want)
+        # more than 16 fields in one call is refused
+        with pytest.raises(engine.RtdError):
+            eng.transfer_fields_init(fields * 3, got_d)
+        for f in fields + own:
+            f.destroy()
+        for p in msgs + [want_d, got_d]:
+            eng.device_free(p)
+
+
 @pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
 def test_in_process_plan_equals_sequential_call(orc, engine, synth, devices):
     """rtd_plan_compute with 1, 2 and 3 handles (threads) on one GPU: bit-identical to rtd_compute on one handle — incoming dose
