@@ -83,6 +83,9 @@ def main():
                     help="N=1 only, not the default: launch consecutive plans round-robin on this many HIP streams, so the kernels of "
                          "independent plans overlap (throughput of a multi-field plan on one GPU; per-kernel durations in stage_ms / "
                          "roofline then include the sharing of the GPU)")
+    ap.add_argument("--exchange-selftest", action="store_true",
+                    help="N=1 only: run the N>1 code path (process group, all-gather, fused slab transfer) with a world of one rank — "
+                         "exercises the RCCL calls on a one-GPU box; not a benchmark mode")
     ap.add_argument("--backend", default="nccl", help="process-group backend; 'gloo' only to rehearse N>1 on a one-GPU box")
     args = ap.parse_args()
 
@@ -96,11 +99,15 @@ def main():
         raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the dose engine has no CPU fallback")
+    xchg = world > 1 or args.exchange_selftest          # the N>1 path (a world of one rank only with --exchange-selftest)
+    if args.exchange_selftest and world == 1:
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(k, v)
     dev_index = local_rank % torch.cuda.device_count()     # one GPU per rank on a real node; shared only in a gloo rehearsal
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    if xchg:
         import torch.distributed as dist
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
@@ -132,15 +139,15 @@ def main():
     n_streams = max(1, args.streams)
     assert n_streams == 1 or world == 1, "--streams is a one-GPU mode"
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else None
-    n_vol = 2 if world > 1 else (n_streams + 1 if n_streams > 1 else 1)
+    n_vol = 2 if xchg else (n_streams + 1 if n_streams > 1 else 1)
     doses = [torch.zeros((n, n, n), dtype=torch.float32, device=dev) for _ in range(n_vol)]
     dose = doses[0]
     # Field objects of the same beam alternate, so plan i+1 is launched before plan i is finished (rtd_field_finish waits for
     # its own field's last kernel only): the device does not idle while the host reads back timing and geometry.
-    flds = [eng.create_field(beam, scn.dims) for _ in range(2 if world > 1 else n_streams + 1)]
+    flds = [eng.create_field(beam, scn.dims) for _ in range(2 if xchg else n_streams + 1)]
     fld = flds[0]
     ex = None
-    if world > 1:
+    if xchg:
         remote = {r: eng.create_field(scn.beams[r], scn.dims, remote=True) for r in range(world) if r != rank}
         ex = plan.BevExchange(dist, rank, world, remote, scn.dims, new_bytes=lambda k: torch.empty(int(k), dtype=torch.uint8, device=dev),
                                zero_box=lambda b, lo, hi: doses[b][lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1].zero_(),
@@ -203,7 +210,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if xchg:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -233,7 +240,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     assert n_timed == args.steps
-    if world > 1:
+    if xchg:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -249,7 +256,7 @@ def main():
         torch.cuda.synchronize()
         lat.append(time.perf_counter() - l0)
     ms_latency = 1000.0 * sum(lat) / len(lat)
-    if world > 1:
+    if xchg:
         tl = torch.tensor([ms_latency], dtype=torch.float64, device=dev)
         dist.all_reduce(tl, op=dist.ReduceOp.MAX)
         ms_latency = float(tl.item())
@@ -258,7 +265,7 @@ def main():
     #      superposition overlaps the next plan's tracer / fill. NOT the headline: `value`, stage_ms and the roofline come from the
     #      single-stream loop above, where a kernel's duration is that of the kernel alone. ----
     multi = None
-    if world == 1 and n_streams == 1:
+    if not xchg and n_streams == 1:
         ns = 3
         ss = [torch.cuda.Stream(device=dev) for _ in range(ns)]
         fl = [eng.create_field(beam, scn.dims) for _ in range(ns)]
@@ -308,12 +315,12 @@ def main():
         f_chk.finish()
     torch.cuda.synchronize()
     clear_ok = torch.tensor([1 if torch.equal(last, ref) else 0], dtype=torch.int64, device=dev)
-    if world > 1:
+    if xchg:
         dist.all_reduce(clear_ok, op=dist.ReduceOp.MIN)
     clear_check = bool(int(clear_ok.item()))
     # (b) N>1: the slabs of all ranks together hold the sum of all fields (each rank also transfers its own field unclipped)
     reduce_check = None
-    if world > 1:
+    if xchg:
         slab_sum = last.sum(dtype=torch.float64).reshape(1)
         ref.zero_()
         f_chk.transfer(ref.data_ptr())
@@ -330,7 +337,7 @@ def main():
         stage_ms = {k: buckets[k] / args.steps for k in buckets if k.endswith("_ms")}
         ct_fp = None
         oracle = None
-        if not args.no_cpu and world == 1:
+        if not args.no_cpu and not xchg:
             from oracle import oracle
             ncpu = args.cpu_threads or min(16, os.cpu_count() or 1)
             oracle.set_threads(ncpu)
@@ -372,7 +379,7 @@ def main():
                        "plans_in_flight_on_streams": n_streams, "ray_grid": info["ray_dims"], "live_steps": info["live_steps"], "max_radius": info["max_radius"],
                        "bbox_voxels": int(np.prod([info["bbox_max"][i] - info["bbox_min"][i] + 1 for i in range(3)])),
                        "ct_footprint_voxels": ct_fp,
-                       "exchange": ("none" if world == 1 else
+                       "exchange": ("none" if not xchg else
                                     "one RCCL all-gather of the packed BEV slabs per plan (%d x %.1f MB), overlapped with the next plan's kernels; every "
                                     "rank writes its slab of the dose volume (axis %d, ranges %s) with all fields, in field order, in one fused launch: the volume stays "
                                     "sharded by slabs, no dose data crosses xGMI; slabs cut for even step times from the ranks' measured field times %s us and "
@@ -416,7 +423,7 @@ def main():
             c1 = time.perf_counter()
             oracle.run_field(c1scn, c1scn.beams[0], c1d, keep_layers=False).close()
             c1_nt = time.perf_counter() - c1
-            host = dose.cpu().numpy() if world == 1 else None
+            host = dose.cpu().numpy() if not xchg else None
             result["cpu_baseline"] = {
                 "value": round(n_cpu_fields * n_vox / cpu_s / 1e6, 3), "unit": "Mvoxels/s", "cores": ncpu, "kind": "port",
                 "cpu_model": cpu_model(),
@@ -471,7 +478,7 @@ def main():
         for f in ex.remote.values():
             f.destroy()
     eng.close()
-    if world > 1:
+    if xchg:
         dist.barrier()
         dist.destroy_process_group()
 

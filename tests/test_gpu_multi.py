@@ -317,3 +317,22 @@ def test_in_process_plan_over_rccl_transport(orc, engine, synth, monkeypatch):
     np.testing.assert_array_equal(dose, want)
     with pytest.raises(engine.RtdError):
         engine.Plan([0, 0])
+
+
+def test_bench_exchange_path_under_rccl_with_one_rank():
+    """bench.py --exchange-selftest: the N>1 code path (nccl process group, all-gathers, packed message, fused slab transfer,
+    pipelining on two volumes) with a world of one rank — what can be run of it on a one-GPU box. The volume it leaves equals the
+    plain transfer of the field bit for bit (reduce_check 0) and the reuse of a dirty volume is clean (clear_check)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--exchange-selftest", "--size", "128", "--steps", "4", "--warmup", "2",
+                        "--no-cpu"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["n_gpus"] == 1 and r["clear_check"] is True and r["reduce_check_rel_err"] == 0.0
+    assert "all-gather" in r["config"]["exchange"] and r["value"] > 0
