@@ -423,6 +423,35 @@ def main():
             c1 = time.perf_counter()
             oracle.run_field(c1scn, c1scn.beams[0], c1d, keep_layers=False).close()
             c1_nt = time.perf_counter() - c1
+            # the reference's OWN CPU code on C1: in water the superposition of a slice is xConvCpuScat + yConvCpu of that slice
+            # (src/cpu_convolution_1d.cpp, compiled where it lies into oracle/_ref/libref.so); timed on one core, checked against
+            # the oracle's superposition stage and against the HIP engine's BEV dose of the same field
+            from oracle import ref_cpu_path
+            ref_leg = None
+            ofc1 = oracle.run_field(c1scn, c1scn.beams[0], np.zeros_like(c1scn.ct), keep_layers=True)
+            kind = "reference" if ref_cpu_path.ref_lib() is not None else "port"
+            sep = ref_cpu_path.separable_bev(ofc1, c1scn.beams[0], which=kind, repeat=20)
+            if sep is not None:
+                sep_bev, sep_s, sep_slices, sep_rad = sep
+                cw, ch, _ = ofc1.info["ray_dims"]
+                obev = ofc1.get("bev").reshape(-1, ch + 64, cw + 64)
+                big = obev > 1e-3 * obev.max()
+                with engine.Engine(dev_index) as e1:
+                    e1.set_luts(es)
+                    e1.set_ct(c1scn.ct)
+                    f1 = e1.create_field(c1scn.beams[0], c1scn.dims)
+                    f1.compute_bev()
+                    f1.finish()
+                    gbev = f1.fetch("bev").reshape(-1, ch + 64, cw + 64)
+                    f1.destroy()
+                sb = sep_bev[:obev.shape[0]].astype(np.float64)
+                ref_leg = {"kind": kind, "cores": 1,
+                           "what": "C1's %d BEV slices (%dx%d rays, radius <= %d) through the reference's xConvCpuScat + yConvCpu%s"
+                                   % (sep_slices, cw, ch, sep_rad, "" if kind == "reference" else " (oracle's restatement: oracle/_ref not built)"),
+                           "seconds": round(sep_s, 4), "bev_mvoxels_s": round(sep_slices * (cw + 2 * sep_rad) * (ch + 2 * sep_rad) / sep_s / 1e6, 1),
+                           "max_rel_diff_oracle_superposition": float((np.abs(sb - obev)[big] / obev[big]).max()),
+                           "max_rel_diff_hip_engine_bev": float((np.abs(sb - gbev)[big] / obev[big]).max())}
+            ofc1.close()
             host = dose.cpu().numpy() if not xchg else None
             result["cpu_baseline"] = {
                 "value": round(n_cpu_fields * n_vox / cpu_s / 1e6, 3), "unit": "Mvoxels/s", "cores": ncpu, "kind": "port",
@@ -433,7 +462,8 @@ def main():
                 "one_thread": {"value": round(n_vox / cpu_1t / 1e6, 3), "unit": "Mvoxels/s", "seconds_per_field": round(cpu_1t, 3), "workload": "C3 field, 1 thread"},
                 "c1": {"workload": "C1: water cube 128^3, one G000 field, one energy layer (BASELINE.json configs[0])",
                        "one_thread_s": round(c1_1t, 4), "all_threads_s": round(c1_nt, 4),
-                       "one_thread_mvox_s": round(c1scn.n_voxels / c1_1t / 1e6, 3), "all_threads_mvox_s": round(c1scn.n_voxels / c1_nt / 1e6, 3)}}
+                       "one_thread_mvox_s": round(c1scn.n_voxels / c1_1t / 1e6, 3), "all_threads_mvox_s": round(c1scn.n_voxels / c1_nt / 1e6, 3)},
+                "reference_cpu_convolution_1d": ref_leg}
             # the timed loop's last volume was cleared by the self-check: recompute the field for the parity leg
             dose.zero_()
             fld.compute(dose.data_ptr())

@@ -1135,6 +1135,23 @@ void orc_x_conv_cpu(const float* in, float* out, float rSigmaEff, unsigned int r
     }
     free(e);
 }
+/* xConvCpuScat (cpu_convolution_1d.cpp:63-89): the scatter form, accumulates into out (which the caller zeroes); unlike the
+ * gather above it fills the left apron too. rad <= inOutOffset is the reference's precondition (it exits otherwise). */
+void orc_x_conv_cpu_scat(const float* in, float* out, float rSigmaEff, unsigned int rad, unsigned int inWidth,
+                         unsigned int outWidth, unsigned int height, unsigned int inOutOffset) {
+    float* e = (float*)malloc(sizeof(float) * (rad + 1));
+    erf_diffs_cpu(rSigmaEff, rad, e);
+    for (unsigned int y = 0; y < height; ++y) {
+        for (unsigned int xIn = 0; xIn < inWidth; ++xIn) {
+            const float val = in[(size_t)y * inWidth + xIn];
+            for (long i = -(long)rad; i < (long)rad + 1; ++i) {
+                long xOut = (long)xIn + (long)inOutOffset + i;
+                out[(size_t)y * outWidth + xOut] += e[labs(i)] * val;
+            }
+        }
+    }
+    free(e);
+}
 void orc_y_conv_cpu(const float* in, float* out, float rSigmaEff, unsigned int rad, unsigned int inHeight,
                     unsigned int width, int inOutOffset) {
     float* e = (float*)malloc(sizeof(float) * (rad + 1));

@@ -62,6 +62,8 @@ void orc_field_free(orc_field f);
 /* uniform-sigma separable convolution (cpu_convolution_1d.cpp) */
 void orc_x_conv_cpu(const float* in, float* out, float rSigmaEff, unsigned int rad, unsigned int inWidth,
                     unsigned int outWidth, unsigned int height, int inOutOffset);
+void orc_x_conv_cpu_scat(const float* in, float* out, float rSigmaEff, unsigned int rad, unsigned int inWidth,
+                         unsigned int outWidth, unsigned int height, unsigned int inOutOffset);
 void orc_y_conv_cpu(const float* in, float* out, float rSigmaEff, unsigned int rad, unsigned int inHeight,
                     unsigned int width, int inOutOffset);
 

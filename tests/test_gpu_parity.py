@@ -338,3 +338,35 @@ def test_lookup_tables_too_large_for_lds(orc, engine, n_samples, n_hu):
     ct, _ = scenarios.hetero_phantom(64)
     scn = scenarios.hetero_ct(big, n=64, spots=5, pitch=7.0, n_layers=3, angles=[15.0], ct=ct)
     _compare_field(orc, engine, scn, scn.beams[0])
+
+
+def test_c1_bev_dose_against_the_reference_cpu_convolution(orc, engine, synth):
+    """BASELINE.json configs[0] (water cube 128^3, one G000 field, one energy layer) against the REFERENCE'S OWN CPU code: in water
+    a BEV slice has one sigma, so its superposition is xConvCpuScat + yConvCpu of the slice (src/cpu_convolution_1d.cpp, compiled from
+    the reference's sources into oracle/_ref/libref.so, which travels to the GPU box as a built file; the oracle's restatement of the
+    two routines, bit-identical to them by golden vector G7, stands in where it is absent). The HIP engine's BEV dose — per-voxel-sigma
+    MFMA superposition, Taylor-series weights — must agree to 2e-5 relative above 1e-3 of the maximum (same weights to ~1e-7, different
+    summation order)."""
+    from oracle import ref_cpu_path
+    scn = scenarios.water_cube(synth, n=128, n_layers=1)
+    ref_dose = np.zeros_like(scn.ct)
+    of = orc.run_field(scn, scn.beams[0], ref_dose, keep_layers=True)
+    which = "reference" if ref_cpu_path.ref_lib() is not None else "port"
+    sep = ref_cpu_path.separable_bev(of, scn.beams[0], which=which)
+    assert sep is not None
+    sep_bev, _, n_slices, max_rad = sep
+    eng, fld, dose, timing, info, d_dose = _run_engine(engine, scn, scn.beams[0])
+    try:
+        W, H, L = info["ray_dims"]
+        gbev = fld.fetch("bev").reshape(-1, H + 64, W + 64)
+        sb = sep_bev[:gbev.shape[0]]
+        assert n_slices > 50 and sb.max() > 0
+        big = sb > 1e-3 * sb.max()
+        rel = np.abs(gbev.astype(np.float64) - sb)[big] / sb[big]
+        print("HIP BEV vs %s CPU convolution: %d slices, radius <= %d, max rel diff %.3g" % (which, n_slices, max_rad, rel.max()))
+        assert rel.max() <= 2e-5
+        assert np.abs(gbev.astype(np.float64) - sb).max() <= 2e-6 * sb.max()
+    finally:
+        fld.destroy()
+        eng.device_free(d_dose)
+        eng.close()

@@ -113,6 +113,9 @@ def test_g7_cpu_convolution_weights(orc):
         xo = np.zeros((H, outW), dtype=np.float32)
         L.orc_x_conv_cpu(P(a), P(xo), C.c_float(rs), rad, inW, outW, H, rad)
         np.testing.assert_array_equal(xo, g["xgather%d" % ci])
+        xs = np.zeros((H, outW), dtype=np.float32)
+        L.orc_x_conv_cpu_scat(P(a), P(xs), C.c_float(rs), rad, inW, outW, H, rad)
+        np.testing.assert_array_equal(xs, g["xscatter%d" % ci])
         yo = np.zeros((H + 2 * rad, inW), dtype=np.float32)
         L.orc_y_conv_cpu(P(a), P(yo), C.c_float(rs), rad, H, inW, rad)
         np.testing.assert_array_equal(yo, g["yscatter%d" % ci])
