@@ -489,7 +489,7 @@ def main():
                         dose_host[:] = 0.0
                         e0 = time.perf_counter()
                         pl.set_luts(es)
-                        pl.set_ct(ct_host)
+                        pl.set_ct(ct_host, deferred=True)     # as the C++ shim does: the CT outlives the call
                         _, pt = pl.compute([beam], dose_host)
                         e2e[name] = {"ms": round(1000.0 * (time.perf_counter() - e0), 3),
                                      "compute_call": {k: round(v, 3) for k, v in pt.items() if k.endswith("_ms")}}
@@ -497,9 +497,11 @@ def main():
             finally:
                 engine.host_unregister(ct_host)
                 engine.host_unregister(dose_host)
-            e2e["what"] = ("LUT + %d MB CT upload, %d MB dose up, all kernels of the field, %d MB dose down; pinned host buffers; first_call "
-                           "includes the workspace allocations (as the reference's per-beam cudaMallocs do), second_call reuses them"
-                           % (ct_host.nbytes // 10 ** 6, dose_host.nbytes // 10 ** 6, dose_host.nbytes // 10 ** 6))
+            e2e["what"] = ("the reference's timed span (kernel_wrapper.cu:410-414 -> 1356-1360) through rtd_plan_* as the C++ shim calls it, pinned host "
+                           "buffers: LUTs up, the box of the %d MB CT that the beam's rays cross up (rtd_plan_set_ct_deferred), the block of the %d MB "
+                           "dose volume that the field can change up, all kernels, that block down; first_call includes the workspace allocations "
+                           "(as the reference's per-beam cudaMallocs do), second_call reuses them. Round-2 start, whole volumes both ways: 30 ms"
+                           % (ct_host.nbytes // 10 ** 6, dose_host.nbytes // 10 ** 6))
             result["ms_plan_end_to_end"] = e2e
         print(json.dumps(result))
     for f in flds:

@@ -181,6 +181,10 @@ int rtd_load_luts_dir(rtd_handle h, const char* dir, int water_cube_test);
 /* CT upload, replaces cudaMemcpy3D into the 3-D texture (kernel_wrapper.cu:420-451).
  * hu_plus_1000: [dims[2]][dims[1]][dims[0]] float, host memory. */
 int rtd_set_ct(rtd_handle h, const float* hu_plus_1000, const uint32_t dims[3]);
+/* rtd_set_ct without the copy: hu_plus_1000 stays with the caller — valid and unchanged until the last compute that uses it has
+ * been finished — and every field uploads, in front of its tracer, only the index box of the volume its rays can sample (a beam
+ * of the 512^3 bench plan reads a tenth of the CT; the upload of all 537 MB was 9.4 of the 13 ms of a one-field call). */
+int rtd_set_ct_deferred(rtd_handle h, const float* hu_plus_1000, const uint32_t dims[3]);
 /* Same, for a CT already resident on this handle's device (not copied, not owned). */
 int rtd_set_ct_device(rtd_handle h, const float* dev_hu_plus_1000, const uint32_t dims[3]);
 
@@ -308,11 +312,12 @@ typedef struct rtd_plan_s* rtd_plan_t;
 typedef struct rtd_plan_timing {
     float total_ms;        /* wall clock of rtd_plan_compute: dose up, all beams, dose down ("Total global execution time
                               (excluding GPU initialisation)", kernel_wrapper.cu:1356-1360)                              */
-    float upload_ms;       /* slowest device: dose slab host -> device                                                   */
+    float upload_ms;       /* slowest device: slab allocation + issuing the upload of the dose block the plan can change (the
+                              copy itself runs beside the kernels; the transfers wait for it)                                */
     float bev_ms;          /* slowest device: its beams up to the BEV dose, slabs exported                               */
     float exchange_ms;     /* slowest device: pulling the other devices' slabs                                          */
-    float transfer_ms;     /* slowest device: transfers of all beams into its slab                                      */
-    float download_ms;     /* slowest device: dose slab device -> host                                                  */
+    float transfer_ms;     /* slowest device: transfers of all beams into its slab (includes waiting for the upload)    */
+    float download_ms;     /* slowest device: the changed block of its slab, device -> host                             */
     int32_t n_devices;
     int32_t reserved[3];
 } rtd_plan_timing;
@@ -323,7 +328,8 @@ const char* rtd_plan_last_error(rtd_plan_t p);
 int rtd_plan_set_options(rtd_plan_t p, const rtd_options* opt);
 int rtd_plan_set_luts(rtd_plan_t p, const rtd_luts* luts);                          /* replicated on every device */
 int rtd_plan_load_luts_dir(rtd_plan_t p, const char* dir, int water_cube_test);
-int rtd_plan_set_ct(rtd_plan_t p, const float* hu_plus_1000, const uint32_t dims[3]); /* replicated, uploads in parallel */
+int rtd_plan_set_ct(rtd_plan_t p, const float* hu_plus_1000, const uint32_t dims[3]);            /* replicated, uploads in parallel */
+int rtd_plan_set_ct_deferred(rtd_plan_t p, const float* hu_plus_1000, const uint32_t dims[3]);   /* rtd_set_ct_deferred on every device */
 /* per_beam_timing: NULL or n_beams records (filled by the device that computed the beam). */
 int rtd_plan_compute(rtd_plan_t p, const rtd_beam* beams, int n_beams, float* dose_inout, const uint32_t dose_dims[3],
                      rtd_timing* per_beam_timing, rtd_plan_timing* plan_timing);

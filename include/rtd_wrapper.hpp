@@ -128,7 +128,8 @@ void cudaWrapperProtons(Image* const imVol, Image* const doseVol, std::vector<Be
     const rtd_luts luts = toLuts(iddData);
     check(rtd_plan_set_luts(g.p, &luts));
     const uint32_t imDims[3] = { imVol->getDims().x, imVol->getDims().y, imVol->getDims().z };
-    check(rtd_plan_set_ct(g.p, imVol->getImData(), imDims));
+    // (deferred: imVol outlives the call, so each beam uploads only the box of the CT its rays cross, in front of its tracer)
+    check(rtd_plan_set_ct_deferred(g.p, imVol->getImData(), imDims));
     const double tBound = wallMs();
     if (fine) outStream << "    Copy data to GPU and bind to textures: " << (tBound - tStart) << " ms\n\n";   // :598
 

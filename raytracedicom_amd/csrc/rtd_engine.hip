@@ -59,6 +59,8 @@ struct rtd_handle_impl {
     float* dCtOwned = nullptr;
     size_t ctOwnedVoxels = 0;     // size of dCtOwned: a CT of the same size is uploaded in place (no free + malloc of the volume)
     uint32_t ctDims[3] = {0, 0, 0};
+    const float* ctHost = nullptr;                 // rtd_set_ct_deferred: the caller's volume, uploaded box by box as fields need it
+    std::vector<std::array<int, 6>> ctBoxes;       // boxes of ctHost already on the device (x0, y0, z0, x1, y1, z1 inclusive)
 };
 
 // what the device allocations of a field depend on: a released workspace is reused by a field with the same signature
@@ -400,6 +402,7 @@ int rtd_set_ct_device(rtd_handle hh, const float* dev, const uint32_t dims[3]) {
     RTD_HIP(h, hipSetDevice(h->device));
     if (h->dCtOwned) { RTD_HIP(h, hipStreamSynchronize(h->stream)); RTD_HIP(h, hipFree(h->dCtOwned)); h->dCtOwned = nullptr; h->ctOwnedVoxels = 0; }
     h->dCt = dev;
+    h->ctHost = nullptr; h->ctBoxes.clear();
     std::memcpy(h->ctDims, dims, sizeof h->ctDims);
     return RTD_OK;
 }
@@ -414,6 +417,23 @@ int rtd_set_ct(rtd_handle hh, const float* host, const uint32_t dims[3]) {   // 
     if (!h->dCtOwned) { RTD_HIP(h, hipMalloc((void**)&h->dCtOwned, n * sizeof(float))); h->ctOwnedVoxels = n; }
     RTD_HIP(h, hipMemcpy(h->dCtOwned, host, n * sizeof(float), hipMemcpyHostToDevice));
     h->dCt = h->dCtOwned;
+    h->ctHost = nullptr; h->ctBoxes.clear();
+    std::memcpy(h->ctDims, dims, sizeof h->ctDims);
+    return RTD_OK;
+}
+
+// rtd_set_ct without the copy: the volume stays with the caller and every field uploads, before its tracer runs, the box of it that
+// its rays can sample (ensureCtBox). A beam reads ~10 % of a 512^3 CT; the reference binds the whole volume (:420-451).
+int rtd_set_ct_deferred(rtd_handle hh, const float* host, const uint32_t dims[3]) {
+    auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
+    if (!h || !host || !dims || !dims[0] || !dims[1] || !dims[2]) return RTD_ERR_INVALID_ARG;
+    RTD_HIP(h, hipSetDevice(h->device));
+    const size_t n = (size_t)dims[0] * dims[1] * dims[2];
+    RTD_HIP(h, hipStreamSynchronize(h->stream));
+    if (h->dCtOwned && h->ctOwnedVoxels != n) { RTD_HIP(h, hipFree(h->dCtOwned)); h->dCtOwned = nullptr; }
+    if (!h->dCtOwned) { RTD_HIP(h, hipMalloc((void**)&h->dCtOwned, n * sizeof(float))); h->ctOwnedVoxels = n; }
+    h->dCt = h->dCtOwned;
+    h->ctHost = host; h->ctBoxes.clear();
     std::memcpy(h->ctDims, dims, sizeof h->ctDims);
     return RTD_OK;
 }
@@ -654,6 +674,45 @@ int rtd_field_create_remote(rtd_handle hh, const rtd_beam* b, const uint32_t dos
 
 // The beam loop body as launches only (kernel_wrapper.cu:766-1218). Asynchronous on the handle's stream.
 // Part 1: everything up to the beam's-eye-view dose (:766-1105).
+// Deferred CT (rtd_set_ct_deferred): the index box of the volume that the field's tracer can sample — the positions
+// start(i, j) + k * inc(i, j) are multilinear in (i, j, k), so their extremes lie at the 8 corners of the ray grid x step range;
+// +-2 voxels cover the interpolation neighbours and the rounding of the accumulated walk — is uploaded unless a box already on the
+// device contains it. Asynchronous, on the handle's stream, in front of the tracer.
+static int ensureCtBox(rtd_handle_impl* h, rtd_field_impl* f) {
+    if (!h->ctHost) return RTD_OK;
+    double lo[3] = {1e30, 1e30, 1e30}, hi[3] = {-1e30, -1e30, -1e30};
+    const int is[2] = {0, f->fc.W - 1}, js[2] = {0, f->fc.H - 1};
+    const double ks[2] = {0.0, (double)(f->fc.S - 1)};
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int c = 0; c < 2; ++c) {
+        const Vec3 st = f->tracer.getStart(is[a], js[b]), inc = f->tracer.getInc(is[a], js[b]);
+        const double p[3] = {st.x + ks[c] * inc.x, st.y + ks[c] * inc.y, st.z + ks[c] * inc.z};
+        for (int d = 0; d < 3; ++d) { lo[d] = std::min(lo[d], p[d]); hi[d] = std::max(hi[d], p[d]); }
+    }
+    std::array<int, 6> box;
+    for (int d = 0; d < 3; ++d) {
+        if (!(lo[d] == lo[d]) || !(hi[d] == hi[d])) { lo[d] = 0; hi[d] = (double)h->ctDims[d]; }     // NaN geometry: the whole axis
+        const double a = std::floor(lo[d]) - 2.0, b = std::floor(hi[d]) + 3.0;
+        box[d] = (int)std::max(a, 0.0);
+        box[3 + d] = (int)std::min(b, (double)h->ctDims[d] - 1.0);
+        if (box[3 + d] < box[d]) return RTD_OK;                       // the beam misses the volume: every sample is BORDER zero
+    }
+    for (const auto& u : h->ctBoxes)
+        if (u[0] <= box[0] && u[1] <= box[1] && u[2] <= box[2] && u[3] >= box[3] && u[4] >= box[4] && u[5] >= box[5]) return RTD_OK;
+    const size_t nx = h->ctDims[0], ny = h->ctDims[1];
+    int x0 = box[0], x1 = box[3];
+    if ((size_t)(x1 - x0 + 1) * 2 >= nx) { x0 = 0; x1 = (int)nx - 1; box[0] = x0; box[3] = x1; }   // wide boxes travel as whole rows
+    hipMemcpy3DParms p;
+    std::memset(&p, 0, sizeof p);
+    p.srcPtr = make_hipPitchedPtr(const_cast<float*>(h->ctHost), nx * sizeof(float), nx, ny);
+    p.dstPtr = make_hipPitchedPtr(h->dCtOwned, nx * sizeof(float), nx, ny);
+    p.srcPos = p.dstPos = make_hipPos((size_t)x0 * sizeof(float), (size_t)box[1], (size_t)box[2]);
+    p.extent = make_hipExtent((size_t)(x1 - x0 + 1) * sizeof(float), (size_t)(box[4] - box[1] + 1), (size_t)(box[5] - box[2] + 1));
+    p.kind = hipMemcpyHostToDevice;
+    RTD_HIP(h, hipMemcpy3DAsync(&p, h->stream));
+    h->ctBoxes.push_back(box);
+    return RTD_OK;
+}
+
 int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
     auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
     auto* f = reinterpret_cast<rtd_field_impl*>(ff);
@@ -661,6 +720,7 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
     if (f->remote) return fail(h, RTD_ERR_INVALID_ARG, "rtd_field_compute_bev: a remote field has no workspace (attach a slab instead)");
     if (!h->dCt || !h->haveLuts) return fail(h, RTD_ERR_NOT_READY, "rtd_field_compute: set LUTs and CT first");
     RTD_HIP(h, hipSetDevice(h->device));   // one host thread may drive handles on several devices
+    { const int st = ensureCtBox(h, f); if (st != RTD_OK) return st; }
     const FieldConst& fc = f->fc;
     hipStream_t s = h->stream;
     const bool timing = h->opt.fine_grained_timing != 0;

@@ -2,13 +2,16 @@
 //
 // The reference's beam loop (src/kernel_wrapper.cu:601) is sequential on one GPU; its beams share nothing but the read-only
 // CT / LUTs and the final `+=` into the dose volume (:92). Here one host thread drives one device:
-//   1. every device uploads ITS z-slab of the caller's dose volume (kernel_wrapper.cu:542 uploads all of it to one GPU);
+//   1. every device holds ITS z-slab of the dose volume, of which only the block the plan can change travels: the bounding box of
+//      the beams' dose boxes inside the slab is uploaded once the boxes are known (after step 2) and downloaded at the end — the
+//      voxels outside it are neither read nor written by any transfer (kernel_wrapper.cu:542 / :1318 move the whole volume both
+//      ways: 2 x 537 MB for a 512^3 grid, 19 of the 30 ms of a one-field call here before this change);
 //   2. beams are dealt round-robin; a device computes the beam's-eye-view (BEV) dose of its beams and packs each into a
 //      message [state record | non-zero block of the BEV cube] (~10 MB for a 512^3 field);
 //   3. every device pulls the messages of the other devices with peer copies over xGMI — the only inter-GPU traffic;
 //   4. every device runs the fan -> dose transfer (primTransfDiv, :69-97) of ALL beams, in beam order, restricted to its
 //      slab: each voxel receives the same `+=` sequence as in the sequential loop, so the result is bit-identical to rtd_compute;
-//   5. every device downloads its slab into the caller's buffer (:1318 downloads all of it from one GPU).
+//   5. every device downloads that block of its slab into the caller's buffer.
 // Built only on the public C ABI of the engine plus the HIP runtime (threads, peer copies).
 #include <hip/hip_runtime.h>
 
@@ -72,7 +75,8 @@ private:
 struct DevSlot {
     int device = 0;
     rtd_handle h = nullptr;
-    hipStream_t copyStream = nullptr;     // pulls of the other devices' messages
+    hipStream_t copyStream = nullptr;     // pulls of the other devices' messages, upload of the dose block
+    hipEvent_t uploaded = nullptr;        // the dose block is on the device (the transfers wait for it)
     float* dSlab = nullptr; size_t slabCap = 0;
     std::vector<void*> msgOut; std::vector<size_t> msgOutCap;   // messages of the beams this device computes
     std::vector<void*> msgIn; std::vector<size_t> msgInCap;     // pulled copies of the other devices' messages
@@ -80,6 +84,26 @@ struct DevSlot {
     std::string error;
     float ms[5] = {0, 0, 0, 0, 0};        // upload, bev, exchange, transfer, download
 };
+
+// Copies the inclusive index box [lo, hi] of a [z][y][x] float volume between the caller's host buffer and a device slab that
+// holds the slices from z0 on (same row and plane pitch): rows of the box when it is narrow, whole x rows (one contiguous run per
+// plane) when it spans most of the row anyway.
+hipError_t copyBox(bool toDevice, float* host, float* dSlab, const uint32_t dims[3], int z0, const int lo[3], const int hi[3], hipStream_t stream) {
+    const size_t nx = dims[0], ny = dims[1];
+    int x0 = lo[0], x1 = hi[0];
+    if ((size_t)(x1 - x0 + 1) * 2 >= nx) { x0 = 0; x1 = (int)nx - 1; }
+    hipMemcpy3DParms p;
+    std::memset(&p, 0, sizeof p);
+    hipPitchedPtr hp = make_hipPitchedPtr(host, nx * sizeof(float), nx, ny);
+    hipPitchedPtr dp = make_hipPitchedPtr(dSlab, nx * sizeof(float), nx, ny);
+    const hipPos hpos = make_hipPos((size_t)x0 * sizeof(float), (size_t)lo[1], (size_t)lo[2]);
+    const hipPos dpos = make_hipPos((size_t)x0 * sizeof(float), (size_t)lo[1], (size_t)(lo[2] - z0));
+    p.srcPtr = toDevice ? hp : dp; p.srcPos = toDevice ? hpos : dpos;
+    p.dstPtr = toDevice ? dp : hp; p.dstPos = toDevice ? dpos : hpos;
+    p.extent = make_hipExtent((size_t)(x1 - x0 + 1) * sizeof(float), (size_t)(hi[1] - lo[1] + 1), (size_t)(hi[2] - lo[2] + 1));
+    p.kind = toDevice ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
+    return hipMemcpy3DAsync(&p, stream);
+}
 
 double nowMs() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -124,7 +148,8 @@ int rtd_plan_create(const int* device_ids, int n_devices, rtd_plan_t* out) {
         s.device = device_ids[d];
         const int st = rtd_create(device_ids[d], &s.h);
         if (st != RTD_OK) { rtd_plan_destroy(p); return st; }       // message: rtd_global_error()
-        if (hipSetDevice(s.device) != hipSuccess || hipStreamCreateWithFlags(&s.copyStream, hipStreamNonBlocking) != hipSuccess) {
+        if (hipSetDevice(s.device) != hipSuccess || hipStreamCreateWithFlags(&s.copyStream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&s.uploaded, hipEventDisableTiming) != hipSuccess) {
             rtd_plan_destroy(p);
             return RTD_ERR_HIP;
         }
@@ -166,6 +191,7 @@ int rtd_plan_destroy(rtd_plan_t p) {
         if (!s.h) continue;
         (void)hipSetDevice(s.device);
         if (s.copyStream) { (void)hipStreamSynchronize(s.copyStream); (void)hipStreamDestroy(s.copyStream); }
+        if (s.uploaded) (void)hipEventDestroy(s.uploaded);
         (void)rtd_sync(s.h);
         if (s.dSlab) (void)rtd_device_free(s.h, s.dSlab);
         for (void* m : s.msgOut) if (m) (void)rtd_device_free(s.h, m);
@@ -192,6 +218,10 @@ int rtd_plan_set_ct(rtd_plan_t p, const float* hu, const uint32_t dims[3]) {
     if (!p || !hu || !dims) return RTD_ERR_INVALID_ARG;
     return onAllDevices(p, [&](DevSlot& s) { return rtd_set_ct(s.h, hu, dims); });
 }
+int rtd_plan_set_ct_deferred(rtd_plan_t p, const float* hu, const uint32_t dims[3]) {
+    if (!p || !hu || !dims) return RTD_ERR_INVALID_ARG;
+    return onAllDevices(p, [&](DevSlot& s) { return rtd_set_ct_deferred(s.h, hu, dims); });
+}
 
 int rtd_plan_compute(rtd_plan_t p, const rtd_beam* beams, int n_beams, float* dose_inout, const uint32_t dose_dims[3],
                      rtd_timing* per_beam, rtd_plan_timing* plan_timing) {
@@ -204,6 +234,7 @@ int rtd_plan_compute(rtd_plan_t p, const rtd_beam* beams, int n_beams, float* do
     // shared between the threads, written before a barrier and read after it
     std::vector<size_t> msgBytes((size_t)n_beams, 0);
     std::vector<void*> msgPtr((size_t)n_beams, nullptr);
+    std::vector<int> boxLo((size_t)n_beams * 3, 0), boxHi((size_t)n_beams * 3, -1);   // the beams' dose boxes (from their owners)
     std::vector<int> failed((size_t)D, 0);
     auto anyFailed = [&] { for (int v : failed) if (v) return true; return false; };
 
@@ -215,7 +246,7 @@ int rtd_plan_compute(rtd_plan_t p, const rtd_beam* beams, int n_beams, float* do
         auto badHip = [&](hipError_t e) { if (e != hipSuccess && s.status == RTD_OK) { s.status = RTD_ERR_HIP; s.error = std::string("HIP error: ") + hipGetErrorString(e); failed[(size_t)d] = 1; } return e != hipSuccess; };
         (void)hipSetDevice(s.device);
         hipStream_t stream = (hipStream_t)rtd_stream(s.h);
-        // ---- 1. this device's z-slab of the volume, uploaded from the caller's buffer (:542) ----
+        // ---- 1. this device's z-slab of the volume (allocation only: what travels is decided after step 2) ----
         const int z0 = (int)((long long)nz * d / D), z1 = (int)((long long)nz * (d + 1) / D) - 1;   // inclusive
         const size_t slabN = (size_t)std::max(z1 - z0 + 1, 0) * nxy;
         double t = nowMs();
@@ -225,12 +256,9 @@ int rtd_plan_compute(rtd_plan_t p, const rtd_beam* beams, int n_beams, float* do
             void* q = nullptr;
             if (!bad(rtd_device_alloc(s.h, slabN * sizeof(float), &q))) { s.dSlab = (float*)q; s.slabCap = slabN; }
         }
-        if (s.status == RTD_OK && slabN)
-            badHip(hipMemcpyAsync(s.dSlab, dose_inout + (size_t)z0 * nxy, slabN * sizeof(float), hipMemcpyHostToDevice, stream));
         // (kernels index the volume by absolute z: the base pointer is shifted so that slice z0 is the slab's first)
         float* doseBase = s.dSlab ? s.dSlab - (size_t)z0 * nxy : nullptr;
         const int32_t clipLo[3] = {0, 0, z0}, clipHi[3] = {(int32_t)dose_dims[0] - 1, (int32_t)dose_dims[1] - 1, z1};
-        if (s.status == RTD_OK) badHip(hipStreamSynchronize(stream));
         s.ms[0] = (float)(nowMs() - t);
 
         // ---- 2. BEV dose of this device's beams; with more than one device, packed for the others ----
@@ -240,9 +268,11 @@ int rtd_plan_compute(rtd_plan_t p, const rtd_beam* beams, int n_beams, float* do
         for (int i = d; i < n_beams && s.status == RTD_OK; i += D, ++slot) {
             if (bad(rtd_field_create(s.h, &beams[i], dose_dims, &mine[(size_t)i]))) break;
             if (bad(rtd_field_compute_bev(s.h, mine[(size_t)i]))) break;
-            if (D == 1 && !(p->useRccl && p->selfMessages)) continue;
             size_t bytes = 0;
-            if (bad(rtd_field_wait_plan(s.h, mine[(size_t)i], nullptr, &bytes))) break;   // the superposition is still running
+            rtd_field_info fi;
+            if (bad(rtd_field_wait_plan(s.h, mine[(size_t)i], &fi, &bytes))) break;   // the superposition is still running
+            for (int a = 0; a < 3; ++a) { boxLo[(size_t)i * 3 + a] = fi.dose_box_min[a]; boxHi[(size_t)i * 3 + a] = fi.dose_box_max[a]; }
+            if (D == 1 && !(p->useRccl && p->selfMessages)) continue;
             if (slot >= s.msgOut.size()) { s.msgOut.push_back(nullptr); s.msgOutCap.push_back(0); }
             if (bytes > s.msgOutCap[slot]) {
                 if (s.msgOut[slot]) (void)rtd_device_free(s.h, s.msgOut[slot]);
@@ -256,6 +286,23 @@ int rtd_plan_compute(rtd_plan_t p, const rtd_beam* beams, int n_beams, float* do
         if (s.status == RTD_OK && (D > 1 || (p->useRccl && p->selfMessages))) bad(rtd_sync(s.h));   // the messages are complete before they travel
         s.ms[1] = (float)(nowMs() - t);
         bar.wait();
+
+        // ---- 1b. upload the block of the slab that the plan can change: bounding box of all beams' dose boxes, cut to the slab ----
+        t = nowMs();
+        int blkLo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, blkHi[3] = {-1, -1, -1};
+        for (int i = 0; i < n_beams; ++i) {
+            const int* lo = &boxLo[(size_t)i * 3]; const int* hi = &boxHi[(size_t)i * 3];
+            if (hi[0] < lo[0] || hi[1] < lo[1] || hi[2] < lo[2]) continue;
+            for (int a = 0; a < 3; ++a) { blkLo[a] = std::min(blkLo[a], lo[a]); blkHi[a] = std::max(blkHi[a], hi[a]); }
+        }
+        blkLo[2] = std::max(blkLo[2], z0); blkHi[2] = std::min(blkHi[2], z1);
+        const bool haveBlock = slabN && blkHi[0] >= blkLo[0] && blkHi[1] >= blkLo[1] && blkHi[2] >= blkLo[2];
+        // on the copy stream, so that it runs beside the superposition kernels still in flight; the transfers wait for its event
+        if (!anyFailed() && haveBlock && s.status == RTD_OK) {
+            if (!badHip(copyBox(true, dose_inout, s.dSlab, dose_dims, z0, blkLo, blkHi, s.copyStream)) && !badHip(hipEventRecord(s.uploaded, s.copyStream)))
+                badHip(hipStreamWaitEvent(stream, s.uploaded, 0));
+        }
+        s.ms[0] += (float)(nowMs() - t);
 
         // ---- 3. exchange of the messages: peer copies over xGMI (same-device slots are read in place), or RCCL broadcasts ----
         t = nowMs();
@@ -308,8 +355,8 @@ int rtd_plan_compute(rtd_plan_t p, const rtd_beam* beams, int n_beams, float* do
 
         // ---- 5. download this device's slab (:1318) — only when every device succeeded: the volume is all-or-nothing ----
         t = nowMs();
-        if (!anyFailed() && slabN) {
-            if (!badHip(hipMemcpyAsync(dose_inout + (size_t)z0 * nxy, s.dSlab, slabN * sizeof(float), hipMemcpyDeviceToHost, stream)))
+        if (!anyFailed() && haveBlock) {
+            if (!badHip(copyBox(false, dose_inout, s.dSlab, dose_dims, z0, blkLo, blkHi, stream)))
                 badHip(hipStreamSynchronize(stream));
         }
         s.ms[4] = (float)(nowMs() - t);

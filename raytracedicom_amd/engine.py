@@ -86,6 +86,8 @@ def lib():
         L.rtd_plan_set_luts.argtypes = [vp, C.POINTER(abi.RtdLuts)]
         L.rtd_plan_load_luts_dir.argtypes = [vp, C.c_char_p, C.c_int]
         L.rtd_plan_set_ct.argtypes = [vp, abi.c_float_p, u3]
+        L.rtd_plan_set_ct_deferred.argtypes = [vp, abi.c_float_p, u3]
+        L.rtd_set_ct_deferred.argtypes = [vp, abi.c_float_p, u3]
         L.rtd_plan_compute.argtypes = [vp, C.POINTER(abi.RtdBeam), C.c_int, abi.c_float_p, u3, C.POINTER(abi.RtdTiming),
                                        C.POINTER(abi.RtdPlanTiming)]
         L.rtd_device_alloc.argtypes = [vp, C.c_size_t, vpp]
@@ -232,7 +234,14 @@ class Engine:
     def load_luts_dir(self, directory, water_cube_test=False):
         self._check(lib().rtd_load_luts_dir(self._h, directory.encode(), int(water_cube_test)))
 
-    def set_ct(self, ct):
+    def set_ct(self, ct, deferred=False):
+        """deferred: rtd_set_ct_deferred — ct (C-contiguous float32, kept alive here) must stay unchanged until the computes that use
+        it are done; each field then uploads only the box of it that its rays cross."""
+        if deferred:
+            assert ct.dtype == np.float32 and ct.flags["C_CONTIGUOUS"]
+            self._ct_keep = ct
+            self._check(lib().rtd_set_ct_deferred(self._h, abi.fptr(ct), abi.uint3((ct.shape[2], ct.shape[1], ct.shape[0]))))
+            return
         ct = abi.f32(ct)
         self._check(lib().rtd_set_ct(self._h, abi.fptr(ct), abi.uint3((ct.shape[2], ct.shape[1], ct.shape[0]))))
 
@@ -320,7 +329,14 @@ class Plan:
         la = es.as_abi()
         self._check(lib().rtd_plan_set_luts(self._h, C.byref(la)))
 
-    def set_ct(self, ct):
+    def set_ct(self, ct, deferred=False):
+        """deferred: rtd_plan_set_ct_deferred — ct (a C-contiguous float32 array, kept alive here) must stay unchanged until the
+        computes that use it are done; each beam then uploads only the box of it that its rays cross."""
+        if deferred:
+            assert ct.dtype == np.float32 and ct.flags["C_CONTIGUOUS"]
+            self._ct_keep = ct
+            self._check(lib().rtd_plan_set_ct_deferred(self._h, abi.fptr(ct), abi.uint3((ct.shape[2], ct.shape[1], ct.shape[0]))))
+            return
         ct = abi.f32(ct)
         self._check(lib().rtd_plan_set_ct(self._h, abi.fptr(ct), abi.uint3((ct.shape[2], ct.shape[1], ct.shape[0]))))
 

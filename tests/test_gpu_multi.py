@@ -336,3 +336,31 @@ def test_bench_exchange_path_under_rccl_with_one_rank():
     r = json.loads(line)
     assert r["n_gpus"] == 1 and r["clear_check"] is True and r["reduce_check_rel_err"] == 0.0
     assert "all-gather" in r["config"]["exchange"] and r["value"] > 0
+
+
+@pytest.mark.parametrize("angles", [(0.0,), (90.0, 37.0, 200.0)])
+def test_deferred_ct_uploads_only_what_the_rays_cross(engine, synth, angles):
+    """rtd_set_ct_deferred / rtd_plan_set_ct_deferred: every field uploads the index box of the CT its tracer can sample. The device
+    volume is poisoned first (a NaN-filled CT of the same size is bound eagerly, so the reused allocation holds NaN wherever no box
+    lands): the dose must still equal the eager path bit for bit — i.e. no sample ever falls outside the uploaded boxes — for
+    parallel and divergent, axis-aligned and oblique beams; the in-process plan moves only the changed block of the dose volume
+    (incoming dose kept, inside and outside that block)."""
+    for dist in ((math.inf, math.inf), (1500.0, 1900.0)):
+        scn = _scn(synth, n=128, angles=angles, dist=dist)
+        base = np.random.default_rng(3).random(scn.ct.shape, dtype=np.float32)
+        want = _sequential(engine, scn, base=base)
+        poison = np.full_like(scn.ct, np.nan)
+        with engine.Engine(0) as eng:
+            eng.set_luts(scn.luts)
+            eng.set_ct(poison)
+            eng.set_ct(scn.ct, deferred=True)
+            got = base.copy()
+            eng.compute(scn.beams, got)
+        np.testing.assert_array_equal(got, want)
+        with engine.Plan([0, 0]) as pl:
+            pl.set_luts(scn.luts)
+            pl.set_ct(poison)
+            pl.set_ct(scn.ct, deferred=True)
+            got = base.copy()
+            pl.compute(scn.beams, got)
+        np.testing.assert_array_equal(got, want)
