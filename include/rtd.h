@@ -152,7 +152,8 @@ typedef struct rtd_field_info {
     int64_t live_steps;           /* sum over layers of (layerFirstPassive - beamFirstInside) */
     int32_t max_radius;           /* largest tile radius over all layers */
     int32_t dose_box_min[3];      /* sub-box of bbox that this field can have changed: the image of the BEV rectangle that */
-    int32_t dose_box_max[3];      /* carries dose (what rtd_field_clear_dose clears; what a multi-GPU plan has to send)     */
+    int32_t dose_box_max[3];      /* carries dose (what rtd_field_clear_dose clears; what has to cross PCIe); with nuclear_corr
+                                     the whole grid (the halo's own box is wider and known on the device only)             */
     int32_t reserved[1];
 } rtd_field_info;
 

@@ -161,6 +161,9 @@ void fillInfo(const rtd_field_impl* f, const FieldState& st, rtd_field_info* inf
     info->beam_first_calculated_passive = st.firstCalculatedPassive;
     for (int i = 0; i < 3; ++i) { info->bbox_min[i] = st.bboxMin[i]; info->bbox_max[i] = st.bboxMax[i]; }
     for (int i = 0; i < 3; ++i) { info->dose_box_min[i] = st.tboxMin[i]; info->dose_box_max[i] = st.tboxMax[i]; }
+    // NUCLEAR_CORR: the halo's slice reaches further sideways than the primary's box and its own box lives on the device only:
+    // report the whole grid (callers that move only the box across PCIe then move everything, as the reference does)
+    if (f->fc.nuclearCorr && !f->remote) for (int i = 0; i < 3; ++i) { info->dose_box_min[i] = 0; info->dose_box_max[i] = (int32_t)f->doseDims[i] - 1; }
     info->live_steps = st.liveSteps; info->max_radius = st.maxRadius;
 }
 
@@ -1106,28 +1109,51 @@ int rtd_compute(rtd_handle hh, const rtd_beam* beams, int n_beams, float* dose_i
     if (!h || !beams || n_beams < 0 || !dose_inout || !dose_dims) return RTD_ERR_INVALID_ARG;
     if (!h->dCt || !h->haveLuts) return fail(h, RTD_ERR_NOT_READY, "rtd_compute: set LUTs and CT first");
     RTD_HIP(h, hipSetDevice(h->device));
-    const size_t n = (size_t)dose_dims[0] * dose_dims[1] * dose_dims[2];
+    const size_t nx = dose_dims[0], ny = dose_dims[1];
+    const size_t n = nx * ny * dose_dims[2];
     float* dDose = nullptr;
     RTD_HIP(h, hipMalloc((void**)&dDose, n * sizeof(float)));
+    // Every beam up to its BEV dose first; then the block of the dose volume that the beams can change — the bounding box of their
+    // dose boxes — goes up, the transfers accumulate into it in beam order, and the same block comes down: the voxels outside
+    // it are neither read nor written (the reference moves the whole volume both ways, :542 / :1318).
+    std::vector<rtd_field> fields((size_t)n_beams, nullptr);
     int st = RTD_OK;
-    hipError_t e = hipMemcpyAsync(dDose, dose_inout, n * sizeof(float), hipMemcpyHostToDevice, h->stream);
-    if (e != hipSuccess) { h->error = hipGetErrorString(e); st = RTD_ERR_HIP; }
+    int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
     for (int i = 0; i < n_beams && st == RTD_OK; ++i) {
-        rtd_field f = nullptr;
-        st = rtd_field_create(hh, &beams[i], dose_dims, &f);
+        st = rtd_field_create(hh, &beams[i], dose_dims, &fields[(size_t)i]);
+        if (st == RTD_OK) st = rtd_field_compute_bev(hh, fields[(size_t)i]);
+        rtd_field_info fi;
+        if (st == RTD_OK) st = rtd_field_wait_plan(hh, fields[(size_t)i], &fi, nullptr);
         if (st != RTD_OK) break;
-        st = rtd_field_compute(hh, f, dDose);
-        if (st == RTD_OK) st = rtd_field_finish(hh, f, timing ? &timing[i] : nullptr, nullptr);
-        std::string keep = h->error;
-        rtd_field_release(hh, f);                                    // the next beam of the same shape reuses the workspace
-        h->error = keep;
+        if (fi.dose_box_max[0] < fi.dose_box_min[0] || fi.dose_box_max[1] < fi.dose_box_min[1] || fi.dose_box_max[2] < fi.dose_box_min[2]) continue;
+        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], (int)fi.dose_box_min[a]); hi[a] = std::max(hi[a], (int)fi.dose_box_max[a]); }
     }
-    if (st == RTD_OK) {
-        e = hipMemcpyAsync(dose_inout, dDose, n * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+    const bool haveBlock = hi[0] >= lo[0] && hi[1] >= lo[1] && hi[2] >= lo[2];
+    hipMemcpy3DParms p;
+    std::memset(&p, 0, sizeof p);
+    if (haveBlock) {
+        if ((size_t)(hi[0] - lo[0] + 1) * 2 >= nx) { lo[0] = 0; hi[0] = (int)nx - 1; }   // wide blocks travel as whole rows
+        p.srcPtr = make_hipPitchedPtr(dose_inout, nx * sizeof(float), nx, ny);
+        p.dstPtr = make_hipPitchedPtr(dDose, nx * sizeof(float), nx, ny);
+        p.srcPos = p.dstPos = make_hipPos((size_t)lo[0] * sizeof(float), (size_t)lo[1], (size_t)lo[2]);
+        p.extent = make_hipExtent((size_t)(hi[0] - lo[0] + 1) * sizeof(float), (size_t)(hi[1] - lo[1] + 1), (size_t)(hi[2] - lo[2] + 1));
+        p.kind = hipMemcpyHostToDevice;
+        if (st == RTD_OK) { const hipError_t e = hipMemcpy3DAsync(&p, h->stream); if (e != hipSuccess) { h->error = hipGetErrorString(e); st = RTD_ERR_HIP; } }
+    }
+    for (int i = 0; i < n_beams && st == RTD_OK; ++i) st = rtd_field_transfer(hh, fields[(size_t)i], dDose, nullptr, nullptr);
+    // device-side errors (radius overflow) surface here; the caller's volume is written only when every beam succeeded
+    for (int i = 0; i < n_beams && st == RTD_OK; ++i) st = rtd_field_finish(hh, fields[(size_t)i], timing ? &timing[i] : nullptr, nullptr);
+    if (st == RTD_OK && haveBlock) {
+        std::swap(p.srcPtr, p.dstPtr);
+        p.kind = hipMemcpyDeviceToHost;
+        hipError_t e = hipMemcpy3DAsync(&p, h->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
         if (e != hipSuccess) { h->error = hipGetErrorString(e); st = RTD_ERR_HIP; }
     }
     (void)hipStreamSynchronize(h->stream);
+    const std::string keep = h->error;
+    for (rtd_field f : fields) if (f) rtd_field_release(hh, f);       // workspaces stay with the handle for the next call
+    h->error = keep;
     (void)hipFree(dDose);
     return st;
 }
