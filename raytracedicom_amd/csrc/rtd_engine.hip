@@ -761,9 +761,15 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
     launchK(k_trace_scan, dim3((unsigned)(f->R / 64)), dim3(64, kScanWaves), scanLds, s, nullptr, ev(1), (const float*)f->dIdd, f->dWepl, fc.W, fc.H,
             (unsigned)fc.S, f->dFirstInside, f->dFirstOutside, f->dState, f->dBlockWeplMin, resetJob);
     k_plan<<<1, 1024, 0, s>>>(f->dState, f->dLayers, (const float*)f->dBlockWeplMin, (int)(f->R / 64), f->dWeplMin, fc);
-    k_conv_x<<<dim3(fc.W / 32, (fc.spotNy + 7) / 8, fc.L), blk, 0, s>>>(f->dSpotWeights, f->dConvInterm, f->dLayers, f->dState, fc);
-    launchK(k_conv_y, dim3(fc.W / 32, fc.H / 8, fc.L), blk, 0, s, nullptr, ev(2), (const float*)f->dConvInterm, f->dRayWeights,
-                          (const LayerPlan*)f->dLayers, (const FieldState*)f->dState, fc);
+    if (fc.spotNy <= kConvMaxRows) {
+        // both passes in one launch, the x pass staged in LDS (k_conv)
+        launchK(k_conv, dim3(fc.W / 32, fc.H / 8, fc.L), blk, (size_t)fc.spotNy * 32 * sizeof(float), s, nullptr, ev(2), (const float*)f->dSpotWeights,
+                f->dRayWeights, (const LayerPlan*)f->dLayers, (const FieldState*)f->dState, fc);
+    } else {
+        k_conv_x<<<dim3(fc.W / 32, (fc.spotNy + 7) / 8, fc.L), blk, 0, s>>>(f->dSpotWeights, f->dConvInterm, f->dLayers, f->dState, fc);
+        launchK(k_conv_y, dim3(fc.W / 32, fc.H / 8, fc.L), blk, 0, s, nullptr, ev(2), (const float*)f->dConvInterm, f->dRayWeights,
+                (const LayerPlan*)f->dLayers, (const FieldState*)f->dState, fc);
+    }
     {
         const size_t fillLds = (size_t)(2 * h->lut.nSamples) * sizeof(float);   // the layer's two cumulative-IDD rows
         const dim3 fillGrid(2 * rayGrid.x * rayGrid.y * fc.L);          // (layer, tile, role) items: sigma walk and dose walk of every tile; placement is decided in the kernel
