@@ -144,7 +144,7 @@ def main():
     dose = doses[0]
     # Field objects of the same beam alternate, so plan i+1 is launched before plan i is finished (rtd_field_finish waits for
     # its own field's last kernel only): the device does not idle while the host reads back timing and geometry.
-    flds = [eng.create_field(beam, scn.dims) for _ in range(2 if xchg else n_streams + 1)]
+    flds = [eng.create_field(beam, scn.dims) for _ in range(3 if xchg else n_streams + 1)]
     fld = flds[0]
     ex = None
     if xchg:
@@ -193,17 +193,33 @@ def main():
             ex.post(f, b)
         in_flight.append((i, f))
 
+    completed = set()                   # N>1: plans whose exchange-side work (all-gather wait + fused slab transfer) has been issued
+
+    def complete_pending():
+        for i, f in in_flight:
+            if i not in completed:
+                ex.complete(f, i % 2, doses[i % 2].data_ptr())
+                completed.add(i)
+
     def retire():
-        """Finish the oldest launched plan. N>1: wait (in stream order) for its all-gather and transfer every field into this rank's
-        slab first."""
+        """Finish the oldest launched plan (N>1: after issuing its slab transfer if that has not happened yet)."""
         i, f = in_flight.pop(0)
-        if ex is not None:
+        if ex is not None and i not in completed:
             ex.complete(f, i % 2, doses[i % 2].data_ptr())
+        completed.discard(i)
         return f.finish()
 
     def step():
-        """One plan iteration in steady state: launch plan i, then finish plan i-1 (pipelined by one)."""
+        """One plan iteration in steady state. N=1: launch plan i, then finish plan i-1 — its last kernel sits in front of plan i's in
+        the stream, so the host never waits with an empty queue. N>1: launch plan i (up to the all-gather), issue the slab transfer of
+        plan i-1 (it waits, in stream order, for that plan's all-gather, which had a whole plan's kernels to finish behind), then
+        finish plan i-2 for the same reason — its transfer was queued in front of plan i's kernels (three field objects alternate)."""
         launch()
+        if ex is not None:
+            complete_pending()
+            if len(in_flight) > 2:
+                return retire()
+            return None
         if len(in_flight) > n_streams:
             return retire()
         return None

@@ -83,7 +83,7 @@ def main():
     doses[0].zero_()
     out = {"n_gpus_emulated": world, "balanced": balanced, "fused_transfer": fused, "steps": steps, "ranks": []}
     for rank in range(world):
-        flds = [eng.create_field(scn.beams[rank], scn.dims) for _ in range(2)]
+        flds = [eng.create_field(scn.beams[rank], scn.dims) for _ in range(3)]
         remote = {r: eng.create_field(scn.beams[r], scn.dims, remote=True) for r in range(world) if r != rank}
         ex = plan.BevExchange(_FakeDist(rank, world, rows, messages), rank, world, remote, scn.dims,
                               new_bytes=lambda k: torch.empty(int(k), dtype=torch.uint8, device=dev),
@@ -94,11 +94,11 @@ def main():
         flds[0].finish()
         for d in doses:
             d.zero_()
-        in_flight, step_no = [], [0]
+        in_flight, step_no, completed = [], [0], set()
 
         def launch():
             i = step_no[0]; step_no[0] += 1
-            f = flds[i % 2]; b = i % 2
+            f = flds[i % 3]; b = i % 2
             if i >= 2:
                 ex.clear(f, b, doses[b].data_ptr())
             f.compute_bev()
@@ -107,12 +107,18 @@ def main():
 
         def retire():
             i, f = in_flight.pop(0)
-            ex.complete(f, i % 2, doses[i % 2].data_ptr())
+            if i not in completed:
+                ex.complete(f, i % 2, doses[i % 2].data_ptr())
+            completed.discard(i)
             return f.finish()
 
-        def step():
+        def step():                                                   # bench.py's N>1 step
             launch()
-            if len(in_flight) > 1:
+            for i, f in in_flight:
+                if i not in completed:
+                    ex.complete(f, i % 2, doses[i % 2].data_ptr())
+                    completed.add(i)
+            if len(in_flight) > 2:
                 retire()
 
         for _ in range(3):
