@@ -154,7 +154,8 @@ typedef struct rtd_field_info {
     int32_t dose_box_min[3];      /* sub-box of bbox that this field can have changed: the image of the BEV rectangle that */
     int32_t dose_box_max[3];      /* carries dose (what rtd_field_clear_dose clears; what has to cross PCIe); with nuclear_corr
                                      the whole grid (the halo's own box is wider and known on the device only)             */
-    int32_t reserved[1];
+    int32_t uniform_sigma;        /* 1: every (layer, step) slice had one sigma over its live rays (a water phantom) and the
+                                     superposition ran as a separable convolution (k_superpose_uniform); decided on the device */
 } rtd_field_info;
 
 typedef struct rtd_handle_s* rtd_handle;

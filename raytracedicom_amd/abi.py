@@ -88,7 +88,7 @@ class RtdFieldInfo(C.Structure):
         ("beam_first_guaranteed_passive", C.c_int32), ("beam_first_calculated_passive", C.c_int32),
         ("bbox_min", C.c_int32 * 3), ("bbox_max", C.c_int32 * 3),
         ("live_steps", C.c_int64), ("max_radius", C.c_int32),
-        ("dose_box_min", C.c_int32 * 3), ("dose_box_max", C.c_int32 * 3), ("reserved", C.c_int32 * 1),
+        ("dose_box_min", C.c_int32 * 3), ("dose_box_max", C.c_int32 * 3), ("uniform_sigma", C.c_int32),
     ]
 
     def as_dict(self):

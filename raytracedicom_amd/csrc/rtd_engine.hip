@@ -47,6 +47,8 @@ struct rtd_handle_impl {
     int numCUs = 256;             // compute units of the device (grid size of the grid-stride kernels)
     bool scanLdsSet = false;      // dynamic-LDS cap of k_trace_scan raised (once per handle)
     size_t traceTLds = 0;         // dynamic-LDS cap set for k_trace_sample_t so far
+    size_t uniLds = 0;            // ... for k_superpose_uniform
+    unsigned inputEpoch = 0;      // bumped whenever CT, LUTs or options change (fields re-test what they learned about their input)
     // LUTs
     bool haveLuts = false;
     std::vector<float> energiesPerU, peakDepths, scaleFacts;
@@ -93,6 +95,11 @@ struct rtd_field_impl {
     LayerPlan* dLayers = nullptr;
     float* dStepTab = nullptr;
     int* dActive = nullptr;      // [L][S][4] minima of (x, y, -x, -y) over rays with dose > 0
+    unsigned int *dSigMin = nullptr, *dSigMax = nullptr;   // [L][S] bits of the smallest / largest tile-uniform sigma^2 (uniform-sigma detection)
+    bool uniformEligible = false; // the separable superposition may take the field (no nuclear halo, BEV height within its accumulators)
+    int uniformHint = -1;         // what the last finished compute found: 0 heterogeneous, 1 one sigma per slice, -1 unknown
+    unsigned hintEpoch = 0;       // ... under this handle->inputEpoch
+    bool triedUniform = false;    // the compute in flight ran the detection
     // NUCLEAR_CORR (default off): the halo on the spot-resolution grid
     int* dNucSpotIdx = nullptr; float *dNucRayWeights = nullptr, *dNucIdd = nullptr, *dNucRs = nullptr, *dNucBev = nullptr;
     int* dNucEffT = nullptr;
@@ -165,6 +172,7 @@ void fillInfo(const rtd_field_impl* f, const FieldState& st, rtd_field_info* inf
     // report the whole grid (callers that move only the box across PCIe then move everything, as the reference does)
     if (f->fc.nuclearCorr && !f->remote) for (int i = 0; i < 3; ++i) { info->dose_box_min[i] = 0; info->dose_box_max[i] = (int32_t)f->doseDims[i] - 1; }
     info->live_steps = st.liveSteps; info->max_radius = st.maxRadius;
+    info->uniform_sigma = st.uniformField;
 }
 
 }  // namespace
@@ -233,6 +241,7 @@ const char* rtd_last_error(rtd_handle hh) {
 
 int rtd_set_options(rtd_handle hh, const rtd_options* opt) {
     auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
+    if (h) ++h->inputEpoch;
     if (!h || !opt) return RTD_ERR_INVALID_ARG;
     h->opt = *opt;
     return RTD_OK;
@@ -304,6 +313,7 @@ int rtd_copy_to_host(rtd_handle hh, void* d, const void* s, size_t bytes) {
 
 int rtd_set_luts(rtd_handle hh, const rtd_luts* l) {   // kernel_wrapper.cu:453-537
     auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
+    if (h) ++h->inputEpoch;
     if (!h || !l) return RTD_ERR_INVALID_ARG;
     if (l->n_energies <= 0 || l->n_energy_samples <= 0 || l->n_density_samples <= 0 || l->n_sp_samples <= 0 ||
         l->n_rrl_samples <= 0 || !l->energies_per_u || !l->peak_depths || !l->scale_facts || !l->cidd_matrix ||
@@ -401,6 +411,7 @@ int rtd_load_luts_dir(rtd_handle hh, const char* dir, int water_cube_test) {   /
 
 int rtd_set_ct_device(rtd_handle hh, const float* dev, const uint32_t dims[3]) {
     auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
+    if (h) ++h->inputEpoch;
     if (!h || !dev || !dims || !dims[0] || !dims[1] || !dims[2]) return RTD_ERR_INVALID_ARG;
     RTD_HIP(h, hipSetDevice(h->device));
     if (h->dCtOwned) { RTD_HIP(h, hipStreamSynchronize(h->stream)); RTD_HIP(h, hipFree(h->dCtOwned)); h->dCtOwned = nullptr; h->ctOwnedVoxels = 0; }
@@ -412,6 +423,7 @@ int rtd_set_ct_device(rtd_handle hh, const float* dev, const uint32_t dims[3]) {
 
 int rtd_set_ct(rtd_handle hh, const float* host, const uint32_t dims[3]) {   // kernel_wrapper.cu:420-451
     auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
+    if (h) ++h->inputEpoch;
     if (!h || !host || !dims || !dims[0] || !dims[1] || !dims[2]) return RTD_ERR_INVALID_ARG;
     RTD_HIP(h, hipSetDevice(h->device));
     const size_t n = (size_t)dims[0] * dims[1] * dims[2];
@@ -429,6 +441,7 @@ int rtd_set_ct(rtd_handle hh, const float* host, const uint32_t dims[3]) {   // 
 // its rays can sample (ensureCtBox). A beam reads ~10 % of a 512^3 CT; the reference binds the whole volume (:420-451).
 int rtd_set_ct_deferred(rtd_handle hh, const float* host, const uint32_t dims[3]) {
     auto* h = reinterpret_cast<rtd_handle_impl*>(hh);
+    if (h) ++h->inputEpoch;
     if (!h || !host || !dims || !dims[0] || !dims[1] || !dims[2]) return RTD_ERR_INVALID_ARG;
     RTD_HIP(h, hipSetDevice(h->device));
     const size_t n = (size_t)dims[0] * dims[1] * dims[2];
@@ -449,7 +462,7 @@ int rtd_field_destroy(rtd_handle hh, rtd_field ff) {
     (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = { f->dSpotWeights, f->dConvInterm, f->dRayWeights, f->dDensity, f->dWepl, f->dRrl, f->dIdd, f->dRSigma, f->dBev, f->dBevPart, f->dNodeCount,
                      f->dFirstInside, f->dFirstOutside, f->dFirstPassive, f->dWeplMin, f->dBlockWeplMin, f->dTileRad,
-                     f->dLayers, f->dState, f->dStepTab, f->dActive, f->dFillDbg,
+                     f->dLayers, f->dState, f->dStepTab, f->dActive, f->dSigMin, f->dSigMax, f->dFillDbg,
                      f->dNucSpotIdx, f->dNucRayWeights, f->dNucIdd, f->dNucRs, f->dNucBev, f->dNucEffT, f->dStateNuc };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (f->hState) (void)hipHostFree(f->hState);
@@ -521,6 +534,7 @@ static int createField(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dim
     fc.ksSigmaCutoff = opt.ks_sigma_cutoff; fc.rayWeightCutoff = opt.ray_weight_cutoff;
     fc.doseToWater = opt.dose_to_water; fc.nozzle = opt.nozzle;
     fc.nuclearCorr = remote ? 0 : opt.nuclear_corr;
+    f->uniformEligible = !remote && !fc.nuclearCorr && fc.bevH <= kUniMaxBevH && L <= 256 && std::getenv("RTD_NO_UNIFORM_PATH") == nullptr;
     fc.nucW = fc.nuclearCorr ? roundTo((int)b->spot_nx, kSuperpTileX) : 0;                                     // :667
     fc.nucH = fc.nuclearCorr ? roundTo((int)b->spot_ny, kSuperpTileY) : 0;
     fc.spotDist = sitg.delta.x / b->ray_spacing[0];                                                            // spotDistInRays, :922
@@ -599,7 +613,7 @@ static int createField(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dim
         f->dDensity = husk->dDensity; f->dWepl = husk->dWepl; f->dRrl = husk->dRrl; f->dIdd = husk->dIdd; f->dRSigma = husk->dRSigma;
         f->dBev = husk->dBev; f->dBevPart = husk->dBevPart; f->dNodeCount = husk->dNodeCount; f->dFirstInside = husk->dFirstInside; f->dFirstOutside = husk->dFirstOutside;
         f->dFirstPassive = husk->dFirstPassive; f->dWeplMin = husk->dWeplMin; f->dBlockWeplMin = husk->dBlockWeplMin; f->dTileRad = husk->dTileRad; f->dLayers = husk->dLayers;
-        f->dState = husk->dState; f->dStepTab = husk->dStepTab; f->dActive = husk->dActive; f->hState = husk->hState; f->dHostState = husk->dHostState;
+        f->dState = husk->dState; f->dStepTab = husk->dStepTab; f->dActive = husk->dActive; f->dSigMin = husk->dSigMin; f->dSigMax = husk->dSigMax; f->hState = husk->hState; f->dHostState = husk->dHostState;
         for (int i = 0; i < 9; ++i) f->ev[i] = husk->ev[i];
         delete husk;
     }
@@ -612,7 +626,7 @@ static int createField(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dim
     A(&f->dBevPart, nOutTiles * kKsTileX * kKsTileY * S * f->ksGroups);
     A(&f->dNodeCount, nOutTiles * S * 32);
     A(&f->dFirstInside, R); A(&f->dFirstOutside, R); A(&f->dFirstPassive, R * L); A(&f->dWeplMin, (size_t)S); A(&f->dBlockWeplMin, (R / 64) * (size_t)S);
-    A(&f->dTileRad, f->tileRadWords * 4); A(&f->dLayers, (size_t)L); A(&f->dState, (size_t)1); A(&f->dStepTab, (size_t)2 * S); A(&f->dActive, (size_t)4 * L * S);
+    A(&f->dTileRad, f->tileRadWords * 4); A(&f->dLayers, (size_t)L); A(&f->dState, (size_t)1); A(&f->dStepTab, (size_t)2 * S); A(&f->dActive, (size_t)4 * L * S); A(&f->dSigMin, (size_t)L * S); A(&f->dSigMax, (size_t)L * S);
     if (st != RTD_OK) { rtd_field_destroy(hh, reinterpret_cast<rtd_field>(f)); return st; }
     hipError_t e = hipMemcpy(f->dSpotWeights, b->spot_weights, nSpot * sizeof(float), hipMemcpyHostToDevice);   // :851
     if (e == hipSuccess) e = hipMemcpy(f->dLayers, f->hLayers.data(), (size_t)L * sizeof(LayerPlan), hipMemcpyHostToDevice);
@@ -724,6 +738,9 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
     if (!h->dCt || !h->haveLuts) return fail(h, RTD_ERR_NOT_READY, "rtd_field_compute: set LUTs and CT first");
     RTD_HIP(h, hipSetDevice(h->device));   // one host thread may drive handles on several devices
     { const int st = ensureCtBox(h, f); if (st != RTD_OK) return st; }
+    // the uniform-sigma detection and kernel are skipped for a field that was found heterogeneous under the same CT / LUTs / options
+    const bool tryUniform = f->uniformEligible && !(f->uniformHint == 0 && f->hintEpoch == h->inputEpoch);
+    f->triedUniform = tryUniform;
     const FieldConst& fc = f->fc;
     hipStream_t s = h->stream;
     const bool timing = h->opt.fine_grained_timing != 0;
@@ -757,7 +774,8 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
         h->scanLdsSet = true;
     }
     const ResetJob resetJob{f->dLayers, fc.L, reinterpret_cast<unsigned int*>(f->dTileRad), f->tileRadWords, f->dActive, (size_t)4 * fc.L * fc.S,
-                            f->dNucIdd, f->dNucRs, fc.nuclearCorr ? (size_t)fc.nucW * fc.nucH * fc.L : (size_t)0};
+                            f->dNucIdd, f->dNucRs, fc.nuclearCorr ? (size_t)fc.nucW * fc.nucH * fc.L : (size_t)0,
+                            f->dSigMin, f->dSigMax, (size_t)fc.L * fc.S};
     launchK(k_trace_scan, dim3((unsigned)(f->R / 64)), dim3(64, kScanWaves), scanLds, s, nullptr, ev(1), (const float*)f->dIdd, f->dWepl, fc.W, fc.H,
             (unsigned)fc.S, f->dFirstInside, f->dFirstOutside, f->dState, f->dBlockWeplMin, resetJob);
     k_plan<<<1, 1024, 0, s>>>(f->dState, f->dLayers, (const float*)f->dBlockWeplMin, (int)(f->R / 64), f->dWeplMin, fc);
@@ -782,7 +800,7 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
         auto launchFill = [&](auto kern, size_t lds) {
             launchK(kern, fillGrid, fillBlk, lds, s, nullptr, ev(3), (const float*)f->dDensity, (const float*)f->dWepl, (const float*)f->dRrl, f->dIdd,
                     f->dRSigma, (const float*)f->dRayWeights, (const int*)f->dFirstInside, (const int*)f->dFirstOutside,
-                    f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc, (const float*)f->dStepTab, f->dActive, h->numCUs, f->dFillDbg, nucFill);
+                    f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc, (const float*)f->dStepTab, f->dActive, h->numCUs, f->dFillDbg, nucFill, f->dSigMin, f->dSigMax, tryUniform ? 1 : 0);
         };
         const bool ldsLut = fillLds <= 40 * 1024;     // + ~17 KiB of static exchange arrays: stays under the 64 KiB default cap of a block's LDS
         if (fc.nuclearCorr) { if (ldsLut) launchFill((k_fill<true, true>), fillLds); else launchFill((k_fill<false, true>), 0); }
@@ -794,11 +812,26 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
                                      f->nucIdxToDoseIdx, f->transfer0Nuc, (int)f->doseDims[0], (int)f->doseDims[1], (int)f->doseDims[2]);
     }
     launchK(k_ks_plan, dim3(1), dim3(256), 0, s, nullptr, f->ev[4], f->dState, f->dLayers, fc, f->rayIdxToDoseIdx, f->transfer0,
-                          (int)f->doseDims[0], (int)f->doseDims[1], (int)f->doseDims[2], f->ksGroups, f->dHostState, f->dStateNuc);
+                          (int)f->doseDims[0], (int)f->doseDims[1], (int)f->doseDims[2], f->ksGroups, f->dHostState, f->dStateNuc,
+                          (const unsigned int*)f->dSigMin, (const unsigned int*)f->dSigMax, tryUniform ? 1 : 0);
     if (fc.nuclearCorr) {
         const int nPix = (fc.nucW + 2 * kMaxSuperpR) * (fc.nucH + 2 * kMaxSuperpR);
         k_nuc_superpose<<<(nPix + 255) / 256, 256, 0, s>>>((const float*)f->dNucIdd, (const float*)f->dNucRs, (const int*)f->dNucEffT,
                                                            (const FieldState*)f->dStateNuc, fc, f->dNucBev);
+    }
+    hipEvent_t ksStart = ev(8);
+    if (tryUniform) {
+        // A field with one sigma per slice (water) is superposed as a separable convolution; whether this field is one is known
+        // on the device only (FieldState::uniformField): the launch returns at once otherwise, k_superpose_mfma below when it is.
+        // A small persistent grid, so that the empty launch of a heterogeneous field costs next to nothing.
+        const size_t uLds = (size_t)(fc.H + kUniTmpPad) * kUniTmpPitch * sizeof(float);   // the x-pass result with its zero rows
+        if (h->uniLds < uLds) {
+            RTD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_superpose_uniform), hipFuncAttributeMaxDynamicSharedMemorySize, (int)uLds));
+            h->uniLds = uLds;
+        }
+        launchK(k_superpose_uniform, dim3((unsigned)h->numCUs * 2), dim3(256), uLds, s, ksStart, nullptr, (const float*)f->dIdd, (const LayerPlan*)f->dLayers,
+                (const FieldState*)f->dState, fc, (const unsigned int*)f->dSigMin, (const float*)f->dStepTab, f->dBev);
+        ksStart = nullptr;
     }
     {
         const int nTX = (fc.bevW + kKsTileX - 1) / kKsTileX, nTY = (fc.bevH + kKsTileY - 1) / kKsTileY;
@@ -807,7 +840,7 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
         // few layers -> few, long work items: deal each item's chunks to 2 or 4 waves (the live items are a fraction of nItems)
         const int split = nItems >= 48 * 1024 ? 1 : (nItems >= 20 * 1024 ? 2 : 4);
         auto launchKs = [&](auto kernel) {
-            launchK(kernel, dim3(nItems), dim3(64 * split), 0, s, ev(8), f->ev[5], (const float*)f->dIdd, (const float*)f->dRSigma,
+            launchK(kernel, dim3(nItems), dim3(64 * split), 0, s, ksStart, f->ev[5], (const float*)f->dIdd, (const float*)f->dRSigma,
                     f->dBevPart, (const unsigned char*)f->dTileRad, (const LayerPlan*)f->dLayers, (const FieldState*)f->dState, fc, nTX, nTY, G,
                     (const int*)f->dActive, f->dBev, f->dNodeCount);
         };
@@ -972,6 +1005,7 @@ int rtd_field_wait_plan(rtd_handle hh, rtd_field ff, rtd_field_info* info, size_
     RTD_HIP(h, hipSetDevice(h->device));
     RTD_HIP(h, hipEventSynchronize(f->ev[4]));
     const FieldState st = *f->hState;                                // mirrored by k_ks_plan into pinned host memory
+    if (f->triedUniform) { f->uniformHint = st.uniformField ? 1 : 0; f->hintEpoch = h->inputEpoch; }
     if (info) fillInfo(f, st, info);
     if (packed_bytes) {
         const int nz = std::max(st.firstCalculatedPassive - st.beamFirstInside, 0);
@@ -1040,6 +1074,7 @@ int rtd_field_finish(rtd_handle hh, rtd_field ff, rtd_timing* timing, rtd_field_
     const int last = f->transferred ? 6 : 5;                         // BEV only: the superposition's reduce is the last kernel
     RTD_HIP(h, hipEventSynchronize(f->ev[last]));
     const FieldState st = *f->hState;                                // mirrored by k_ks_plan into pinned host memory
+    if (f->triedUniform) { f->uniformHint = st.uniformField ? 1 : 0; f->hintEpoch = h->inputEpoch; }
     if (timing) {
         std::memset(timing, 0, sizeof *timing);
         RTD_HIP(h, hipEventElapsedTime(&timing->total_ms, f->ev[0], f->ev[last]));

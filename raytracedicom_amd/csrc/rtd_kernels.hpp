@@ -64,6 +64,10 @@ struct FieldState {
     // slice = slice slabFirst of the buffer. The field's own BEV buffer: (0, 0, bevW, bevH, beamFirstInside); a slab exported
     // by k_pack_bev for another GPU: the rectangle that carries dose, slices from 0.
     int packX0, packY0, packW, packH, slabFirst;
+    // Uniform-sigma fields (water): k_fill raises nonUniform when the live rays of a (layer, step, tile) differ in sigma^2; k_ks_plan
+    // sets uniformField when no tile did and every depositing (layer, step) slice has ONE sigma^2 over all its tiles — the
+    // superposition of such a slice is a separable convolution (k_superpose_uniform) and k_superpose_mfma stands aside.
+    int nonUniform, uniformField;
     unsigned short fillItems[2 * 256];      // (layer << 1 | role) of k_fill's walks by descending cost (k_plan), for its block placement
     unsigned char tileOrder[kKsMaxOrder];   // superposition dispatch order of the output tiles: most source rays in reach first
 };
@@ -189,7 +193,7 @@ __device__ inline float sample3dBorder(const float* __restrict__ vol, int nx, in
 __device__ inline void resetFieldScalars(FieldState* st) {
     st->beamFirstInside = 0x7fffffff; st->beamFirstOutside = -0x7fffffff; st->firstGuaranteedPassive = 0;
     st->firstCalculatedPassive = 0; st->errorFlags = 0; st->maxRadius = 0; st->liveSteps = 0;
-    st->empty = 0;
+    st->empty = 0; st->nonUniform = 0; st->uniformField = 0;
     for (int i = 0; i < 4; ++i) st->actUnion[i] = 0x7fffffff;
     for (int i = 0; i < 3; ++i) { st->bboxMin[i] = 0; st->bboxMax[i] = 0; st->tboxMin[i] = 0; st->tboxMax[i] = -1; }
 }
@@ -198,6 +202,7 @@ struct ResetJob {
     unsigned int* tileRadWords; size_t nRadWords;
     int* active; size_t nActive;
     float* nucIdd; float* nucRs; size_t nNuc;      // NUCLEAR_CORR: (0, inf) = the reference's fills at kernel_wrapper.cu:862-863
+    unsigned int* sigMin; unsigned int* sigMax; size_t nSig;   // per (layer, step): bits of the smallest / largest tile-uniform sigma^2
 };
 __device__ inline void resetFieldArrays(const ResetJob& j, size_t t, size_t nT) {
     for (size_t l = t; l < (size_t)j.L; l += nT) {
@@ -207,6 +212,7 @@ __device__ inline void resetFieldArrays(const ResetJob& j, size_t t, size_t nT) 
     for (size_t i = t; i < j.nRadWords; i += nT) j.tileRadWords[i] = 0xFFFFFFFFu;    // every (layer, step, tile): "not classified"
     for (size_t i = t; i < j.nActive; i += nT) j.active[i] = 0x7f7f7f7f;             // empty dose rectangles (+large minima)
     for (size_t i = t; i < j.nNuc; i += nT) { j.nucIdd[i] = 0.0f; j.nucRs[i] = __int_as_float(0x7f800000); }
+    for (size_t i = t; i < j.nSig; i += nT) { j.sigMin[i] = 0x7f800000u; j.sigMax[i] = 0u; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -691,13 +697,15 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
                                                const int* __restrict__ firstOutside, int* __restrict__ firstPassive,
                                                unsigned char* __restrict__ tileRad, LayerPlan* layers, FieldState* st,
                                                LutView lut, FillGeom fg, FieldConst fc, const float* __restrict__ stepTab,
-                                               int* __restrict__ active, int nCU, long long* __restrict__ dbg, NucFill nuc) {
+                                               int* __restrict__ active, int nCU, long long* __restrict__ dbg, NucFill nuc,
+                                               unsigned int* __restrict__ sigMin, unsigned int* __restrict__ sigMax, int trackUniform) {
     extern __shared__ float sLutF[];                                 // dose walk: the layer's two cumulative-IDD rows
     // diagnostic build only (RTD_FILL_DEBUG): per block start / end clock, hardware id, item — no output value depends on it
     const long long dbgT0 = dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
     __shared__ float sSig[2][kFillBatch][256];                       // sigma walk: [buffer][step][ray] sigmaSq of the rays with a finite 1/sigma (-1: none)
     __shared__ unsigned long long sDoseMask[2][kFillBatch][4];       // dose walk: [buffer][step][wave] ballot of the rays that carry dose
     __shared__ int sHist[kMaxSuperpR + 2];
+    __shared__ int sUni;                                             // sigma walk: every tile of this block so far had ONE sigma^2 over its live rays
 
     // Block placement. The walks differ in cost — the number of steps per layer (150..210 on C3), and a sigma walk is ~1.5 dose
     // walks — while only 2*L*tiles blocks exist (5.2 per CU on C3), so a plain grid leaves the kernel waiting for the CUs that
@@ -746,6 +754,7 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
     if (role == 0) {
         // ================================ sigma walk ================================
         if (tid < kMaxSuperpR + 2) sHist[tid] = 0;
+        if (tid == 0) sUni = trackUniform;                           // 0: the field is known not to be uniform (or not eligible): nothing is tracked
         const float pInv = 0.5649718f, eCoef = 8.639415f;
         // E_s^2 and the empirical widening per NUCLEAR_CORR variant (kernel_wrapper.cu:228-245)
         const float eRefSq = !NUC ? 198.81f : fc.nuclearCorr == 1 ? 190.44f : fc.nuclearCorr == 2 ? 216.09f : fc.nuclearCorr == 3 ? 169.00f : 198.81f;
@@ -811,10 +820,28 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
             __syncthreads();                                         // the only barrier of a batch (sSig is double-buffered)
             {   // fused tileRadCalc: radius class of every (layer, step, tile) of the batch, 32 lanes per step
                 const int j = tid >> 5, l = tid & 31;                // step of the batch, lane of its 32-lane group
+                // (uniform-sigma detection, while the block has seen nothing else: the smallest sigma^2 of the live rays as well —
+                //  a block of a heterogeneous field drops this after its first batch)
+                const bool uni = sUni != 0;                          // block-uniform (written before the previous batch's barrier)
+                const float inf = __int_as_float(0x7f800000);
                 float m = sSig[buf][j][l];
+                float mn = m >= 0.0f ? m : inf;
 #pragma unroll
-                for (int k = 1; k < 8; ++k) { const float t = sSig[buf][j][l + 32 * k]; m = t > m ? t : m; }
+                for (int k = 1; k < 8; ++k) {
+                    const float t = sSig[buf][j][l + 32 * k];
+                    m = t > m ? t : m;
+                    if (uni) { const float tl = t >= 0.0f ? t : inf; mn = tl < mn ? tl : mn; }
+                }
                 m = -halfWaveMin(-m);                                // lanes 31 / 63 hold the maximum of their 32-lane half
+                if (uni) mn = halfWaveMin(mn);
+                if (uni && l == 31 && step0 + j < pAfterLast && m >= 0.0f) {
+                    if (mn != m) { sUni = 0; st->nonUniform = 1; }
+                    else {
+                        const size_t si = (size_t)layer * fc.S + step0 + j;
+                        atomicMin(&sigMin[si], __float_as_uint(m));  // (sigma^2 >= 0: the bit patterns order like the values)
+                        atomicMax(&sigMax[si], __float_as_uint(m));
+                    }
+                }
                 if (l == 31 && step0 + j < pAfterLast) {
                     // tile minimum of 1/sigma (= the reference's minVal, kernel_wrapper.cuh:282-297) from the tile maximum of
                     // sigmaSq with IEEE sqrt and division, then the class exactly as the reference computes it (:300-305)
@@ -999,7 +1026,8 @@ __device__ inline void transferBoxes(const FromFan& rayIdxToDoseIdx, int W, int 
 // (:955-957) + transfer bounding box and shift (:1185-1213), all on the device.
 __global__ __launch_bounds__(256) void k_ks_plan(FieldState* stGlobal, LayerPlan* layers, FieldConst fc, FromFan rayIdxToDoseIdx, TransferParams tp0,
                                                  int doseNx, int doseNy, int doseNz, int G, FieldState* __restrict__ hostMirror,
-                                                 FieldState* __restrict__ stNuc) {
+                                                 FieldState* __restrict__ stNuc, const unsigned int* __restrict__ sigMin,
+                                                 const unsigned int* __restrict__ sigMax, int uniformEligible) {
     // The state record is completed in LDS and then written out — to device memory and to its pinned host mirror — by all threads,
     // one dword each per trip: this one-block launch sits on the field's critical path, and both a load of the record behind a
     // store to it and a serial copy over PCIe by one thread cost microseconds each.
@@ -1008,12 +1036,13 @@ __global__ __launch_bounds__(256) void k_ks_plan(FieldState* stGlobal, LayerPlan
     __shared__ int sGroup[32];
     __shared__ int sMaxRad;
     __shared__ unsigned long long sLive;
+    __shared__ int sSliceDiffers;
     {
         const unsigned int* src = reinterpret_cast<const unsigned int*>(stGlobal);
         unsigned int* dst = reinterpret_cast<unsigned int*>(&sSt);
         for (unsigned int i = threadIdx.x; i < sizeof(FieldState) / 4; i += blockDim.x) dst[i] = src[i];
     }
-    if (threadIdx.x == 0) { sMaxPassive = 0; sMaxRad = 0; sLive = 0ull; }
+    if (threadIdx.x == 0) { sMaxPassive = 0; sMaxRad = 0; sLive = 0ull; sSliceDiffers = 0; }
     if (threadIdx.x < 32) sGroup[threadIdx.x] = 0;
     __syncthreads();
     FieldState* st = &sSt;
@@ -1046,6 +1075,24 @@ __global__ __launch_bounds__(256) void k_ks_plan(FieldState* stGlobal, LayerPlan
         atomicMax(&sMaxPassive, p.layerFirstPassive);
         atomicMax(&sGroup[l % G], p.layerFirstPassive);
         if (p.layerFirstPassive > first) atomicAdd(&sLive, (unsigned long long)(p.layerFirstPassive - first));
+    }
+    __syncthreads();
+    // Uniform-sigma field (water)? No tile saw two sigma^2 (k_fill) and every depositing (layer, step) has one over all its tiles.
+    // A heterogeneous field leaves here at the first test.
+    const bool maybeUniform = uniformEligible && !st->nonUniform && !st->errorFlags;
+    if (maybeUniform) {
+        // (entries of steps outside [first, layerFirstPassive) still hold the reset values (+inf, 0) or a uniform tile's value: the
+        //  test "+inf or equal" needs no step range, and with four pairs of loads in flight the 2 x L x S words cost ~5 us)
+        int differs = 0;
+        const int n = fc.L * fc.S;
+        for (int i0 = threadIdx.x; i0 < n; i0 += 4 * blockDim.x) {
+            unsigned int a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = i0 + u * blockDim.x; a[u] = i < n ? sigMin[i] : 0x7f800000u; b[u] = i < n ? sigMax[i] : 0u; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (a[u] != 0x7f800000u && a[u] != b[u]) differs = 1;   // (+inf: no live ray)
+        }
+        if (differs) atomicOr(&sSliceDiffers, 1);
     }
     __syncthreads();
     {   // Output tiles of the superposition ranked by the number of dose-carrying rays within reach: the work items of the
@@ -1085,6 +1132,7 @@ __global__ __launch_bounds__(256) void k_ks_plan(FieldState* stGlobal, LayerPlan
             transferBoxes(rayIdxToDoseIdx, fc.W, fc.H, first, calcPassive, bevLo, bevHi, first, calcPassive, doseNx, doseNy, doseNz,
                           bboxMin, bboxMax, tboxMin, tboxMax);
         st->firstCalculatedPassive = calcPassive;
+        st->uniformField = (maybeUniform && !sSliceDiffers) ? 1 : 0;
         st->maxRadius = sMaxRad;
         for (int gI = 0; gI < 32; ++gI) st->groupPassive[gI] = sGroup[gI];
         st->bevLo[0] = bevLo[0]; st->bevLo[1] = bevLo[1]; st->bevHi[0] = bevHi[0]; st->bevHi[1] = bevHi[1];
@@ -1259,6 +1307,7 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
     const int tX = tile % nTX, tY = tile / nTX;
     const int first = st->beamFirstInside, calcPassive = st->firstCalculatedPassive;
     if (st->errorFlags) return;                                      // radius overflow: the reference throws before any superposition (kernel_wrapper.cu:965)
+    if (st->uniformField) return;                                    // one sigma per slice: k_superpose_uniform has written the BEV dose
     if (k < 0 || k < first || k >= calcPassive) return;
     const int li = lane & 15, kq = lane >> 4;                         // MFMA 16x16x4: A[i=li][k=kq], B[k=kq][j=li]
     const int ox0 = tX * kKsTileX, oy0 = tY * kKsTileY;               // padded BEV coordinates of the owned tile
@@ -1567,6 +1616,181 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
                 const int oy = oy0 + 16 * ty + 4 * kq + reg, ox = ox0 + 16 * tx + li;
                 if (oy < fc.bevH && ox < fc.bevW) out[(size_t)oy * fc.bevW + ox] = acc[ty][tx][reg];
             }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7u: the superposition of a field whose every (layer, step) slice has ONE sigma over its live rays — a water phantom, the
+// reference's own WATER_CUBE_TEST. There the per-voxel-sigma patches of kernelSuperposition (kernel_wrapper.cuh:432-489) add up to
+// a separable convolution of the slice with that layer's pixel-integrated Gaussian: an x pass and a y pass, 2 (2 rho + 1)
+// multiply-adds per pixel instead of (2 rho + 1)^2 — what the reference's CPU path does (cpu_convolution_1d.cpp: xConvCpuScat +
+// yConvCpu), and the HIP result is checked against exactly that code (tests/test_gpu_parity.py, C1). Whether a field qualifies
+// is decided on the device (k_fill / k_ks_plan: FieldState::uniformField); this launch returns at once otherwise, and
+// k_superpose_mfma does when it does not.
+// Work item = (slice k, strip of 32 BEV columns), a persistent grid strides over them. Both passes are banded Toeplitz products on
+// the matrix cores (v_mfma_f32_16x16x4_f32): with w[u] = e[|u - rho|] (the same pixel integrals as k_superpose_mfma: Taylor series
+// for sigma >= 1.4 px, erf differences below; zeros around it),
+//   x pass  tmp[r][c]  = sum_k in[r][k] * w[k - c]      A = 32 ray rows at a time staged in LDS, B = the Toeplitz band
+//   y pass  out[y][c]  = sum_k w[k - y] * tmp[k][c]     A = the band, B = tmp in LDS (zero rows above and below)
+// 16 + 2 rho + 1 values of k per 16 x 16 block. The item's depositing layers are listed first (their plan records fetched in
+// parallel, not one dependent chain per layer). Per layer and 32-row chunk a wave stages 8 rows (its lanes the staged columns lane,
+// lane + 64: 16 loads in flight, no per-element index arithmetic) and owns one block of the chunk's x pass (two accumulation
+// chains over alternate k steps); in the y pass the band operand is the same for every block, so a wave runs its up to 8 blocks as
+// independent chains behind one band load per k step. The layers are added in ascending order: reproducible.
+// (History on the reference's water cube, where k_superpose_mfma takes 1.18 ms: vector-ALU version with a sliding window 0.71 ms
+// and first matrix version 0.67 ms — both spent their time in a staging loop of one dependent load per trip; everything staged
+// into registers and every loop unrolled: 1.2 - 1.5 ms — instruction fetch, 14 k lines of code.)
+constexpr int kUniMaxBevH = 256;                                     // 16 row blocks x 2 column blocks = 8 accumulator tiles per wave
+constexpr int kUniInPitch = 101;                                     // row pitch of the staged chunk: >= 32 + 2 rho + 4 columns, odd
+constexpr int kUniTmpPad = 164;                                      // rows of the x-pass result beside the H ray rows: 64 above, the y pass's reach below
+constexpr int kUniTmpPitch = 33;                                     // (odd: the four k rows of a B operand fall into different banks)
+__global__ __launch_bounds__(256) void k_superpose_uniform(const float* __restrict__ bevIdd, const LayerPlan* __restrict__ layers,
+                                                            const FieldState* __restrict__ st, FieldConst fc,
+                                                            const unsigned int* __restrict__ sigMin, const float* __restrict__ stepTab,
+                                                            float* __restrict__ bevDose) {
+    if (!st->uniformField || st->errorFlags) return;
+    extern __shared__ float sTmp[];                                  // [64 + H + 100][33]: x-pass result, zero rows above and below
+    __shared__ float sIn[32 * kUniInPitch];                          // the chunk's ray rows, columns x0 ...
+    __shared__ float sWp[16 + 2 * kMaxSuperpR + 8 + 16];             // w[u] at [16 + u], zeros on both sides
+    __shared__ int sLay[256], sRho[256], sCount[4];
+    __shared__ float sRs[256];
+    const int t = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, li = lane & 15, kq = lane >> 4;
+    const int W = fc.W, H = fc.H;
+    const int first = st->beamFirstInside, nSlices = st->firstCalculatedPassive - first;
+    const int nStrips = (fc.bevW + 31) / 32;
+    const int nTilesY = 2 * ((fc.bevH + 15) / 16);                   // 16 x 16 output blocks of a strip (<= 32)
+    const size_t memStep = (size_t)W * H;
+    for (int i = t; i < (H + kUniTmpPad) * kUniTmpPitch; i += 256) sTmp[i] = 0.0f;   // (the x pass only ever writes rows [64, 64 + H))
+    __syncthreads();
+    for (int item = blockIdx.x; item < nStrips * nSlices; item += gridDim.x) {
+        const int k = first + item / nStrips, s = item % nStrips;
+        // ---- the item's depositing layers, ascending, with their 1/sigma and batch radius (thread l looks at layer l) ----
+        {
+            bool on = false; float rs = 0.0f; int rho = 0;
+            if (t < fc.L && k < layers[t].layerFirstPassive) {
+                const unsigned int bits = sigMin[(size_t)t * fc.S + k];
+                if (bits != 0x7f800000u) {                            // (+inf as stored by the reset: no live ray in this slice)
+                    const float sig2 = __uint_as_float(bits);
+                    const float sqrt2 = 1.41421356f;
+                    // 1/sigma of the slice's rays with k_fill's operations (same bits as its per-ray values); class and batch radius as there
+                    rs = stepTab[2 * k] * __builtin_amdgcn_rcpf(sqrt2 * (__builtin_amdgcn_sqrtf(sig2) + 0.21f));
+                    const float minRs = stepTab[2 * k] / (sqrt2 * (sqrtf(sig2) + 0.21f));
+                    int cls = f2iSat(fc.ksSigmaCutoff / (sqrtf(2.0f) * minRs) + 0.5f);
+                    cls = cls > kMaxSuperpR ? kMaxSuperpR : (cls < 0 ? 0 : cls);
+                    rho = layers[t].effRad[cls];
+                    on = true;
+                }
+            }
+            const unsigned long long mask = __ballot(on);
+            if (lane == 0) sCount[wv] = __popcll(mask);
+            __syncthreads();                                         // (also: the previous item is done with the lists)
+            int pos = __popcll(mask & ((1ull << lane) - 1ull));
+            for (int w2 = 0; w2 < wv; ++w2) pos += sCount[w2];
+            if (on) { sLay[pos] = t; sRho[pos] = rho; sRs[pos] = rs; }
+            __syncthreads();
+        }
+        const int nA = sCount[0] + sCount[1] + sCount[2] + sCount[3];
+        f32x4 acc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int a = 0; a < nA; ++a) {
+            const int rho = sRho[a];
+            const float rs = sRs[a];
+            const int nU = (2 * rho + 1 + 3) & ~3, nC = 32 + nU;     // band length padded to whole k steps; staged columns
+            if (t < 16 + nU + 16) {
+                float w = 0.0f;
+                const int u = t - 16;
+                if (u >= 0 && u <= 2 * rho) {
+                    const int ii = u < rho ? rho - u : u - rho;
+                    if (rs <= 0.5f) {                                 // Taylor series of the pixel integral (see k_superpose_mfma)
+                        const float h2 = rs * rs, h4 = h2 * h2;
+                        const float k1 = h2 * (1.0f / 24.0f), k2 = h4 * (1.0f / 1920.0f), k3 = h4 * h2 * (1.0f / 322560.0f);
+                        const float c0 = 1.0f - 2.0f * k1 + 12.0f * k2 - 120.0f * k3;
+                        const float c1 = (4.0f * k1 - 48.0f * k2 + 720.0f * k3) * h2;
+                        const float c2 = (16.0f * k2 - 480.0f * k3) * h4;
+                        const float c3 = 64.0f * k3 * (h4 * h2);
+                        const float wq = (float)(ii * ii);
+                        const float gq = 0.5641895835f * rs * __builtin_amdgcn_exp2f(-1.4426950409f * h2 * wq);
+                        w = gq * __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(c3, wq, c2), wq, c1), wq, c0);
+                    } else {
+                        w = ii == 0 ? erff(rs * 0.5f) : 0.5f * (erff(rs * ((float)ii + 0.5f)) - erff(rs * ((float)ii - 0.5f)));
+                    }
+                }
+                sWp[t] = w;
+            }
+            // staging geometry: staged column c <-> ray column x0 + c; this lane's two columns
+            const int x0 = 32 * s - 32 - rho;
+            const int xa = x0 + lane, xb = xa + 64;
+            const bool okA = lane < nC && xa >= 0 && xa < W, okB = lane + 64 < nC && xb >= 0 && xb < W;
+            const int ia = okA ? xa : 0, ib = okB ? xb : 0;           // (a valid column for the lanes that load nothing)
+            const float* __restrict__ idd = bevIdd + ((size_t)sLay[a] * fc.S + k) * memStep;
+            const int rb = wv >> 1, cb = wv & 1;
+            for (int r0 = 0; r0 < H; r0 += 32) {
+                // ---- stage rows r0 + wv, r0 + wv + 4, ... (8 per wave): all 16 loads in flight, then the LDS stores ----
+                float va[8], vb[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int y = r0 + wv + 4 * i;
+                    const size_t ro = (size_t)(y < H ? y : 0) * W;
+                    va[i] = idd[ro + ia]; vb[i] = idd[ro + ib];
+                    if (!(okA && y < H)) va[i] = 0.0f;
+                    if (!(okB && y < H)) vb[i] = 0.0f;
+                }
+                __syncthreads();                                     // weights written / previous chunk consumed
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float* d0 = sIn + (size_t)(wv + 4 * i) * kUniInPitch + lane;
+                    d0[0] = va[i];
+                    if (lane + 64 < nC) d0[64] = vb[i];
+                }
+                __syncthreads();
+                // ---- x pass of the chunk: this wave's block (row half rb, column half cb), two chains over alternate k steps ----
+                f32x4 d0 = {0.0f, 0.0f, 0.0f, 0.0f}, d1 = {0.0f, 0.0f, 0.0f, 0.0f};
+                const float* aRow = sIn + (size_t)(16 * rb + li) * kUniInPitch + 16 * cb + kq;
+                const float* bw = &sWp[16 + kq - li];
+                int kk0 = 0;
+                for (; kk0 + 8 <= 16 + nU; kk0 += 8) {
+                    const float a0 = aRow[kk0], b0 = bw[kk0], a1 = aRow[kk0 + 4], b1 = bw[kk0 + 4];
+                    d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, d0, 0, 0, 0);
+                    d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, d1, 0, 0, 0);
+                }
+                if (kk0 < 16 + nU) d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aRow[kk0], bw[kk0], d0, 0, 0, 0);
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int r = r0 + 16 * rb + 4 * kq + reg;
+                    if (r < H) sTmp[(size_t)(64 + r) * kUniTmpPitch + 16 * cb + li] = d0[reg] + d1[reg];
+                }
+            }
+            __syncthreads();
+            // ---- y pass: out[y] = sum_u w[u] tmp[y - 32 - rho + u] (tmp row y sits at 64 + y): blocks wv, wv + 4, ... of the strip ----
+            {
+                const float* aw = &sWp[16 + kq - li];
+                // block wv + 4 q = (row block (wv >> 1) + 2 q, column half wv & 1): one pointer per k step, the blocks at constant offsets
+                const float* bRow = sTmp + (size_t)(32 - rho + kq + 16 * (wv >> 1)) * kUniTmpPitch + 16 * (wv & 1) + li;
+                const int nQ = (nTilesY - wv + 3) >> 2;               // this wave's blocks (wave-uniform)
+                for (int kk0 = 0; kk0 < 16 + nU; kk0 += 4, bRow += 4 * kUniTmpPitch) {
+                    const float av = aw[kk0];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        if (q < nQ) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bRow[(size_t)q * 32 * kUniTmpPitch], acc[q], 0, 0, 0);
+                }
+            }
+            __syncthreads();                                         // this layer's weights and x-pass result are consumed
+        }
+        float* out = bevDose + (size_t)k * fc.bevW * fc.bevH;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int tIdx = wv + 4 * q;
+            if (tIdx < nTilesY) {
+                const int ox = 32 * s + 16 * (tIdx & 1) + li;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int oy = 16 * (tIdx >> 1) + 4 * kq + reg;
+                    if (oy < fc.bevH && ox < fc.bevW) out[(size_t)oy * fc.bevW + ox] = acc[q][reg];
+                }
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -124,6 +124,7 @@ def test_c3_hetero_512_bench_workload(orc, engine, synth, ct512):
     scn = scenarios.hetero_ct(synth, n=512, angles=[0.0], ct=ct512)
     dose, ref, timing, info = _compare_field(orc, engine, scn, scn.beams[0])
     assert info["ray_dims"] == [96, 88, 20] and info["live_steps"] > 3000
+    assert info["uniform_sigma"] == 0                                # heterogeneous CT: per-voxel-sigma superposition
 
 
 @pytest.mark.parametrize("deg", [90.0, 180.0, 270.0])
@@ -363,6 +364,7 @@ def test_c1_bev_dose_against_the_reference_cpu_convolution(orc, engine, synth):
         assert n_slices > 50 and sb.max() > 0
         big = sb > 1e-3 * sb.max()
         rel = np.abs(gbev.astype(np.float64) - sb)[big] / sb[big]
+        assert info["uniform_sigma"] == 1                            # water: the separable superposition kernel took the field
         print("HIP BEV vs %s CPU convolution: %d slices, radius <= %d, max rel diff %.3g" % (which, n_slices, max_rad, rel.max()))
         assert rel.max() <= 2e-5
         assert np.abs(gbev.astype(np.float64) - sb).max() <= 2e-6 * sb.max()
@@ -370,3 +372,42 @@ def test_c1_bev_dose_against_the_reference_cpu_convolution(orc, engine, synth):
         fld.destroy()
         eng.device_free(d_dose)
         eng.close()
+
+
+def test_uniform_sigma_path_equals_the_general_superposition(orc, engine, synth, monkeypatch):
+    """A water field is superposed by k_superpose_uniform (one sigma per slice: separable convolution), decided on the device. With
+    the path disabled (RTD_NO_UNIFORM_PATH, read at field creation) the same field goes through k_superpose_mfma: both BEV doses agree
+    to rounding (same weights, different order of the sums), both are within the parity tolerance of the oracle, and the dose too.
+    A beam that leaves the water (air gap in the CT) is NOT uniform and must take the general path by itself."""
+    scn = scenarios.water_cube(synth, n=128, n_layers=3)
+    ref = np.zeros_like(scn.ct)
+    of = orc.run_field(scn, scn.beams[0], ref, keep_layers=True)
+    W, H, L = of.info["ray_dims"]
+    obev = of.get("bev").reshape(-1, H + 64, W + 64)
+    res = {}
+    for name, env in (("uniform", None), ("general", "1")):
+        if env is None:
+            monkeypatch.delenv("RTD_NO_UNIFORM_PATH", raising=False)
+        else:
+            monkeypatch.setenv("RTD_NO_UNIFORM_PATH", env)
+        eng, fld, dose, timing, info, d_dose = _run_engine(engine, scn, scn.beams[0])
+        try:
+            assert info["uniform_sigma"] == (1 if env is None else 0)
+            res[name] = (fld.fetch("bev").reshape(-1, H + 64, W + 64).copy(), dose.copy())
+        finally:
+            fld.destroy(); eng.device_free(d_dose); eng.close()
+    monkeypatch.delenv("RTD_NO_UNIFORM_PATH", raising=False)
+    bu, du = res["uniform"]; bg, dg = res["general"]
+    big = obev > 1e-3 * obev.max()
+    assert (np.abs(bu.astype(np.float64) - bg)[big] / obev[big]).max() <= 1e-5
+    np.testing.assert_array_equal(bu == 0, bg == 0)                  # same support: same radii
+    for b in (bu, bg):
+        _rel_close(b, obev, rtol=1e-4)
+    _rel_close(du, ref, rtol=1e-4)
+    _rel_close(dg, ref, rtol=1e-4)
+    # half of the water replaced by a density step across the field: slices are no longer uniform
+    ct2 = scn.ct.copy()
+    ct2[:, :, : ct2.shape[2] // 2] *= 1.3
+    scn2 = scenarios.Scenario("water with a density step", scn.luts, ct2, scn.spacing, scn.beams)
+    dose2, ref2, timing, info = _compare_field(orc, engine, scn2, scn2.beams[0])
+    assert info["uniform_sigma"] == 0
