@@ -1633,8 +1633,9 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
 //   y pass  out[y][c]  = sum_k w[k - y] * tmp[k][c]     A = the band, B = tmp in LDS (zero rows above and below)
 // 16 + 2 rho + 1 values of k per 16 x 16 block. The item's depositing layers are listed first (their plan records fetched in
 // parallel, not one dependent chain per layer). Per layer and 32-row chunk a wave stages 8 rows (its lanes the staged columns lane,
-// lane + 64: 16 loads in flight, no per-element index arithmetic) and owns one block of the chunk's x pass (two accumulation
-// chains over alternate k steps); in the y pass the band operand is the same for every block, so a wave runs its up to 8 blocks as
+// lane + 64: 16 loads in flight, no per-element index arithmetic; the next chunk — of this or the next layer — is fetched into
+// registers while this one is on the matrix cores, two LDS buffers alternate, one barrier per chunk) and owns one block of the
+// chunk's x pass (two accumulation chains over alternate k steps); in the y pass the band operand is the same for every block, so a wave runs its up to 8 blocks as
 // independent chains behind one band load per k step. The layers are added in ascending order: reproducible.
 // (History on the reference's water cube, where k_superpose_mfma takes 1.18 ms: vector-ALU version with a sliding window 0.71 ms
 // and first matrix version 0.67 ms — both spent their time in a staging loop of one dependent load per trip; everything staged
@@ -1649,7 +1650,7 @@ __global__ __launch_bounds__(256) void k_superpose_uniform(const float* __restri
                                                             float* __restrict__ bevDose) {
     if (!st->uniformField || st->errorFlags) return;
     extern __shared__ float sTmp[];                                  // [64 + H + 100][33]: x-pass result, zero rows above and below
-    __shared__ float sIn[32 * kUniInPitch];                          // the chunk's ray rows, columns x0 ...
+    __shared__ float sIn[2 * 32 * kUniInPitch];                      // two buffers of a chunk's ray rows, columns x0 ...
     __shared__ float sWp[16 + 2 * kMaxSuperpR + 8 + 16];             // w[u] at [16 + u], zeros on both sides
     __shared__ int sLay[256], sRho[256], sCount[4];
     __shared__ float sRs[256];
@@ -1693,6 +1694,27 @@ __global__ __launch_bounds__(256) void k_superpose_uniform(const float* __restri
         f32x4 acc[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) acc[q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        // Chunk (layer a of the list, ray rows r0 ...) into registers: wave wv takes rows r0 + wv, r0 + wv + 4, ... (8 per wave), its
+        // lanes the staged columns lane and lane + 64 (staged column c <-> ray column x0 + c): 16 loads in flight, no per-element
+        // index arithmetic.
+        float va[8], vb[8];
+        auto fetchChunk = [&](int a, int r0) {
+            const int rho = sRho[a], nC = 32 + ((2 * rho + 1 + 3) & ~3), x0 = 32 * s - 32 - rho;
+            const int xa = x0 + lane, xb = xa + 64;
+            const bool okA = lane < nC && xa >= 0 && xa < W, okB = lane + 64 < nC && xb >= 0 && xb < W;
+            const int ia = okA ? xa : 0, ib = okB ? xb : 0;           // (a valid column for the lanes that load nothing)
+            const float* __restrict__ idd = bevIdd + ((size_t)sLay[a] * fc.S + k) * memStep;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int y = r0 + wv + 4 * i;
+                const size_t ro = (size_t)(y < H ? y : 0) * W;
+                va[i] = idd[ro + ia]; vb[i] = idd[ro + ib];
+                if (!(okA && y < H)) va[i] = 0.0f;
+                if (!(okB && y < H)) vb[i] = 0.0f;
+            }
+        };
+        int bufSel = 0;
+        if (nA > 0) fetchChunk(0, 0);
         for (int a = 0; a < nA; ++a) {
             const int rho = sRho[a];
             const float rs = sRs[a];
@@ -1718,35 +1740,23 @@ __global__ __launch_bounds__(256) void k_superpose_uniform(const float* __restri
                 }
                 sWp[t] = w;
             }
-            // staging geometry: staged column c <-> ray column x0 + c; this lane's two columns
-            const int x0 = 32 * s - 32 - rho;
-            const int xa = x0 + lane, xb = xa + 64;
-            const bool okA = lane < nC && xa >= 0 && xa < W, okB = lane + 64 < nC && xb >= 0 && xb < W;
-            const int ia = okA ? xa : 0, ib = okB ? xb : 0;           // (a valid column for the lanes that load nothing)
-            const float* __restrict__ idd = bevIdd + ((size_t)sLay[a] * fc.S + k) * memStep;
+            // ---- x pass, 32 ray rows at a time. The chunk that is about to be used sits in registers (fetched while the previous
+            //      chunk — or the previous layer's y pass — was on the matrix cores): registers -> LDS buffer, barrier, fetch the
+            //      next chunk, matrix work on this one. One barrier per chunk; the two LDS buffers alternate. ----
             const int rb = wv >> 1, cb = wv & 1;
             for (int r0 = 0; r0 < H; r0 += 32) {
-                // ---- stage rows r0 + wv, r0 + wv + 4, ... (8 per wave): all 16 loads in flight, then the LDS stores ----
-                float va[8], vb[8];
+                float* buf = sIn + (size_t)bufSel * (32 * kUniInPitch);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const int y = r0 + wv + 4 * i;
-                    const size_t ro = (size_t)(y < H ? y : 0) * W;
-                    va[i] = idd[ro + ia]; vb[i] = idd[ro + ib];
-                    if (!(okA && y < H)) va[i] = 0.0f;
-                    if (!(okB && y < H)) vb[i] = 0.0f;
-                }
-                __syncthreads();                                     // weights written / previous chunk consumed
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    float* d0 = sIn + (size_t)(wv + 4 * i) * kUniInPitch + lane;
+                    float* d0 = buf + (size_t)(wv + 4 * i) * kUniInPitch + lane;
                     d0[0] = va[i];
                     if (lane + 64 < nC) d0[64] = vb[i];
                 }
-                __syncthreads();
-                // ---- x pass of the chunk: this wave's block (row half rb, column half cb), two chains over alternate k steps ----
+                __syncthreads();                                     // chunk and weights visible; the other buffer's readers are past it
+                if (r0 + 32 < H) fetchChunk(a, r0 + 32); else if (a + 1 < nA) fetchChunk(a + 1, 0);
+                // this wave's block of the chunk (row half rb, column half cb), two chains over alternate k steps
                 f32x4 d0 = {0.0f, 0.0f, 0.0f, 0.0f}, d1 = {0.0f, 0.0f, 0.0f, 0.0f};
-                const float* aRow = sIn + (size_t)(16 * rb + li) * kUniInPitch + 16 * cb + kq;
+                const float* aRow = buf + (size_t)(16 * rb + li) * kUniInPitch + 16 * cb + kq;
                 const float* bw = &sWp[16 + kq - li];
                 int kk0 = 0;
                 for (; kk0 + 8 <= 16 + nU; kk0 += 8) {
@@ -1760,6 +1770,7 @@ __global__ __launch_bounds__(256) void k_superpose_uniform(const float* __restri
                     const int r = r0 + 16 * rb + 4 * kq + reg;
                     if (r < H) sTmp[(size_t)(64 + r) * kUniTmpPitch + 16 * cb + li] = d0[reg] + d1[reg];
                 }
+                bufSel ^= 1;
             }
             __syncthreads();
             // ---- y pass: out[y] = sum_u w[u] tmp[y - 32 - rho + u] (tmp row y sits at 64 + y): blocks wv, wv + 4, ... of the strip ----
