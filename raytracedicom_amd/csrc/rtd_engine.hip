@@ -741,6 +741,9 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
     // the uniform-sigma detection and kernel are skipped for a field that was found heterogeneous under the same CT / LUTs / options
     const bool tryUniform = f->uniformEligible && !(f->uniformHint == 0 && f->hintEpoch == h->inputEpoch);
     f->triedUniform = tryUniform;
+    // ... and a field that was found uniform under the same inputs will be found uniform again (the test is exact arithmetic on
+    // the same values): the general superposition kernel, all of whose ~10^5 blocks would only look at the flag and leave, is not launched
+    const bool knownUniform = tryUniform && f->uniformHint == 1 && f->hintEpoch == h->inputEpoch;
     const FieldConst& fc = f->fc;
     hipStream_t s = h->stream;
     const bool timing = h->opt.fine_grained_timing != 0;
@@ -829,11 +832,11 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
             RTD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_superpose_uniform), hipFuncAttributeMaxDynamicSharedMemorySize, (int)uLds));
             h->uniLds = uLds;
         }
-        launchK(k_superpose_uniform, dim3((unsigned)h->numCUs * 2), dim3(256), uLds, s, ksStart, nullptr, (const float*)f->dIdd, (const LayerPlan*)f->dLayers,
+        launchK(k_superpose_uniform, dim3((unsigned)h->numCUs * 2), dim3(256), uLds, s, ksStart, knownUniform ? f->ev[5] : nullptr, (const float*)f->dIdd, (const LayerPlan*)f->dLayers,
                 (const FieldState*)f->dState, fc, (const unsigned int*)f->dSigMin, (const float*)f->dStepTab, f->dBev);
         ksStart = nullptr;
     }
-    {
+    if (!knownUniform) {
         const int nTX = (fc.bevW + kKsTileX - 1) / kKsTileX, nTY = (fc.bevH + kKsTileY - 1) / kKsTileY;
         const int G = f->ksGroups;
         const int nItems = fc.S * G * nTY * nTX;

@@ -411,3 +411,30 @@ def test_uniform_sigma_path_equals_the_general_superposition(orc, engine, synth,
     scn2 = scenarios.Scenario("water with a density step", scn.luts, ct2, scn.spacing, scn.beams)
     dose2, ref2, timing, info = _compare_field(orc, engine, scn2, scn2.beams[0])
     assert info["uniform_sigma"] == 0
+    # One field object across computes: what it learned about its input (uniform: the general kernel is not even launched the next
+    # time; heterogeneous: no detection, no separable launch) must not outlive that input — a new CT on the handle resets it.
+    n = scn.n_voxels
+    with engine.Engine(0) as eng:
+        eng.set_luts(scn.luts)
+        eng.set_ct(scn.ct)
+        d = eng.device_alloc(4 * n)
+        fld = eng.create_field(scn.beams[0], scn.dims)
+        outs = []
+        for ct_now, want_uniform in ((None, 1), (None, 1), (ct2, 0), (ct2, 0), (scn.ct, 1), (scn.ct, 1)):
+            if ct_now is not None:
+                eng.set_ct(ct_now)
+            eng.device_zero(d, 4 * n)
+            fld.compute(d)
+            _, info = fld.finish()
+            assert info["uniform_sigma"] == want_uniform
+            h = np.empty_like(scn.ct)
+            eng.to_host(h, d)
+            outs.append(h)
+        np.testing.assert_array_equal(outs[0], du)
+        np.testing.assert_array_equal(outs[1], du)
+        np.testing.assert_array_equal(outs[2], dose2)
+        np.testing.assert_array_equal(outs[3], dose2)
+        np.testing.assert_array_equal(outs[4], du)
+        np.testing.assert_array_equal(outs[5], du)
+        fld.destroy()
+        eng.device_free(d)
