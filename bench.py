@@ -83,9 +83,11 @@ def main():
                     help="N=1 only, not the default: launch consecutive plans round-robin on this many HIP streams, so the kernels of "
                          "independent plans overlap (throughput of a multi-field plan on one GPU; per-kernel durations in stage_ms / "
                          "roofline then include the sharing of the GPU)")
-    ap.add_argument("--no-secondary", action="store_true",
-                    help="skip the secondary 3-stream throughput leg (for profiler passes: its overlapped kernels would enter the per-kernel "
-                         "averages of rocprofv3 --stats beside the timed single-stream loop)")
+    ap.add_argument("--secondary", action="store_true",
+                    help="also run the secondary 3-stream throughput leg (throughput_3_streams). Not in the default run: its overlapped kernels "
+                         "would enter the per-kernel averages of a `rocprofv3 --stats -- python bench.py` beside the timed single-stream loop, "
+                         "whose kernel durations are what `roofline` reports")
+    ap.add_argument("--no-secondary", action="store_true", help=argparse.SUPPRESS)   # (accepted for older command lines: the default now)
     ap.add_argument("--exchange-selftest", action="store_true",
                     help="N=1 only: run the N>1 code path (process group, all-gather, fused slab transfer) with a world of one rank — "
                          "exercises the RCCL calls on a one-GPU box; not a benchmark mode")
@@ -284,7 +286,7 @@ def main():
     #      superposition overlaps the next plan's tracer / fill. NOT the headline: `value`, stage_ms and the roofline come from the
     #      single-stream loop above, where a kernel's duration is that of the kernel alone. ----
     multi = None
-    if not xchg and n_streams == 1 and not args.no_secondary:
+    if not xchg and n_streams == 1 and args.secondary:
         ns = 3
         ss = [torch.cuda.Stream(device=dev) for _ in range(ns)]
         fl = [eng.create_field(beam, scn.dims) for _ in range(ns)]
