@@ -1637,6 +1637,9 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
 // registers while this one is on the matrix cores, two LDS buffers alternate, one barrier per chunk) and owns one block of the
 // chunk's x pass (two accumulation chains over alternate k steps); in the y pass the band operand is the same for every block, so a wave runs its up to 8 blocks as
 // independent chains behind one band load per k step. The layers are added in ascending order: reproducible.
+// Per-phase clock stamps (one wave per block): y pass 31 %, x pass 22 %, requesting the next chunk 21 % and moving it to LDS 16 %
+// of the time — in front of each matrix LOOP the compiler waits for every load in flight, so the requests do not hide behind the
+// matrix work as intended (unrolling the loops to avoid that made the code slower: 0.45 and 2.0 ms); the matrix cores are busy 19 %.
 // (History on the reference's water cube, where k_superpose_mfma takes 1.18 ms: vector-ALU version with a sliding window 0.71 ms
 // and first matrix version 0.67 ms — both spent their time in a staging loop of one dependent load per trip; everything staged
 // into registers and every loop unrolled: 1.2 - 1.5 ms — instruction fetch, 14 k lines of code.)
@@ -1698,6 +1701,8 @@ __global__ __launch_bounds__(256) void k_superpose_uniform(const float* __restri
         // lanes the staged columns lane and lane + 64 (staged column c <-> ray column x0 + c): 16 loads in flight, no per-element
         // index arithmetic.
         float va[8], vb[8];
+        bool preOkA = false, preOkB = false;
+        int preR0 = 0;
         auto fetchChunk = [&](int a, int r0) {
             const int rho = sRho[a], nC = 32 + ((2 * rho + 1 + 3) & ~3), x0 = 32 * s - 32 - rho;
             const int xa = x0 + lane, xb = xa + 64;
@@ -1708,10 +1713,9 @@ __global__ __launch_bounds__(256) void k_superpose_uniform(const float* __restri
             for (int i = 0; i < 8; ++i) {
                 const int y = r0 + wv + 4 * i;
                 const size_t ro = (size_t)(y < H ? y : 0) * W;
-                va[i] = idd[ro + ia]; vb[i] = idd[ro + ib];
-                if (!(okA && y < H)) va[i] = 0.0f;
-                if (!(okB && y < H)) vb[i] = 0.0f;
-            }
+                va[i] = idd[ro + ia]; vb[i] = idd[ro + ib];           // (not touched here: the values are masked when they go to LDS —
+            }                                                         //  a select on them would wait for the loads on the spot)
+            preOkA = okA; preOkB = okB; preR0 = r0;
         };
         int bufSel = 0;
         if (nA > 0) fetchChunk(0, 0);
@@ -1749,8 +1753,9 @@ __global__ __launch_bounds__(256) void k_superpose_uniform(const float* __restri
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     float* d0 = buf + (size_t)(wv + 4 * i) * kUniInPitch + lane;
-                    d0[0] = va[i];
-                    if (lane + 64 < nC) d0[64] = vb[i];
+                    const bool rowIn = preR0 + wv + 4 * i < H;
+                    d0[0] = (preOkA && rowIn) ? va[i] : 0.0f;
+                    if (lane + 64 < nC) d0[64] = (preOkB && rowIn) ? vb[i] : 0.0f;
                 }
                 __syncthreads();                                     // chunk and weights visible; the other buffer's readers are past it
                 if (r0 + 32 < H) fetchChunk(a, r0 + 32); else if (a + 1 < nA) fetchChunk(a + 1, 0);
