@@ -411,6 +411,10 @@ def test_uniform_sigma_path_equals_the_general_superposition(orc, engine, synth,
     scn2 = scenarios.Scenario("water with a density step", scn.luts, ct2, scn.spacing, scn.beams)
     dose2, ref2, timing, info = _compare_field(orc, engine, scn2, scn2.beams[0])
     assert info["uniform_sigma"] == 0
+    # a divergent beam into the same water: the rays' step lengths differ, so do their sigmas — general path, same parity bar
+    scn3 = scenarios.water_cube(synth, n=128, n_layers=3, source_dist=(1800.0, 2200.0))
+    dose3, ref3, timing, info = _compare_field(orc, engine, scn3, scn3.beams[0])
+    assert info["uniform_sigma"] == 0
     # One field object across computes: what it learned about its input (uniform: the general kernel is not even launched the next
     # time; heterogeneous: no detection, no separable launch) must not outlive that input — a new CT on the handle resets it.
     n = scn.n_voxels
