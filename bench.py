@@ -395,8 +395,9 @@ def main():
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C3: %d^3 synthetic heterogeneous CT (HU->density/SP LUTs), %d field(s) one per GPU, "
-                                   "10x10 spots x 20 layers = 2000 spots, 512 tracer steps, 1 mm rays" % (n, world),
+            "config": {"workload": "%s: %d^3 synthetic heterogeneous CT (HU->density/SP LUTs), %d field(s) one per GPU, "
+                                   "10x10 spots x 20 layers = 2000 spots, 512 tracer steps, 1 mm rays"
+                                   % ("C5" if n == 768 else ("C3" if world == 1 else "C4") if n == 512 else "size %d" % n, n, world),
                        "plans_in_flight_on_streams": n_streams, "ray_grid": info["ray_dims"], "live_steps": info["live_steps"], "max_radius": info["max_radius"],
                        "bbox_voxels": int(np.prod([info["bbox_max"][i] - info["bbox_min"][i] + 1 for i in range(3)])),
                        "ct_footprint_voxels": ct_fp,
