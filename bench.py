@@ -397,7 +397,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %d^3 synthetic heterogeneous CT (HU->density/SP LUTs), %d field(s) one per GPU, "
                                    "10x10 spots x 20 layers = 2000 spots, 512 tracer steps, 1 mm rays"
-                                   % ("C5" if n == 768 else ("C3" if world == 1 else "C4") if n == 512 else "size %d" % n, n, world),
+                                   % ("C5" if n == 768 else ("C3" if world == 1 else "C4" if world == 4 else "C3 fields at %d angles" % world) if n == 512 else "size %d" % n, n, world),
                        "plans_in_flight_on_streams": n_streams, "ray_grid": info["ray_dims"], "live_steps": info["live_steps"], "max_radius": info["max_radius"],
                        "bbox_voxels": int(np.prod([info["bbox_max"][i] - info["bbox_min"][i] + 1 for i in range(3)])),
                        "ct_footprint_voxels": ct_fp,
