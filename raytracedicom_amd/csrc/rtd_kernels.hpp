@@ -123,6 +123,14 @@ __device__ inline float halfWaveMin(float v) {
 }
 __device__ inline int waveMinI(int v) { return waveReduce(v, [](int a, int b) { return b < a ? b : a; }); }
 __device__ inline int waveMaxI(int v) { return waveReduce(v, [](int a, int b) { return b > a ? b : a; }); }
+// Workgroup barrier that orders LDS only: __syncthreads() also waits for every global load in flight (its fence covers all address
+// spaces: s_waitcnt vmcnt(0) in front of s_barrier), which defeats a prefetch that is meant to stay in flight across the barrier.
+// For barriers that hand over LDS data only.
+__device__ inline void ldsBarrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 __device__ inline int roundToI(int v, int m) { return ((v + m - 1) / m) * m; }   // roundTo, kernel_wrapper.cu:45-48
 __device__ inline int f2iSat(float v) { return (int)v; }   // v_cvt_i32_f32: NaN -> 0, saturating (same as the reference GPU)
 
@@ -413,7 +421,7 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_trace_scan(const float* __r
                 for (int j = 0; j < kU; ++j) if (v[j] > 150.0f) lastInside = (int)(c0 + j0 + j);
             }
         }
-        __syncthreads();                                             // chunk walked
+        ldsBarrier();                                                // chunk walked
 #pragma unroll
         for (int j = 0; j < kScanPerWave; ++j) {                     // all waves store the chunk's WEPL
             const unsigned int i = c0 + wv * kScanPerWave + j;
@@ -427,9 +435,9 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_trace_scan(const float* __r
             }
         }
         if (c0 + kScanChunk < steps) {
-            __syncthreads();                                         // chunk stored: the buffer takes the next one
+            ldsBarrier();                                            // chunk stored: the buffer takes the next one
             stage(buf);
-            __syncthreads();
+            ldsBarrier();
         }
     }
     if (wv == 1) {
@@ -817,7 +825,7 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
                 (bevRSigmaEff + layerOff + (size_t)stepNo * memStep)[rayOff] = rSigmaEff;
                 sSig[buf][j][tid] = sig;
             }
-            __syncthreads();                                         // the only barrier of a batch (sSig is double-buffered)
+            ldsBarrier();                                            // the only barrier of a batch (sSig is double-buffered)
             {   // fused tileRadCalc: radius class of every (layer, step, tile) of the batch, 32 lanes per step
                 const int j = tid >> 5, l = tid & 31;                // step of the batch, lane of its 32-lane group
                 // (uniform-sigma detection, while the block has seen nothing else: the smallest sigma^2 of the live rays as well —
@@ -938,7 +946,7 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
 #pragma unroll
                 for (int j = 0; j < kFillBatch; ++j) sDoseMask[buf][j][wave] = doseMask[j];
             }
-            __syncthreads();                                         // the only barrier of a batch (sDoseMask is double-buffered)
+            ldsBarrier();                                            // the only barrier of a batch (sDoseMask is double-buffered)
             // rectangle of the tile's rays that carry dose at step j, as minima of (x, y, -x, -y): lanes 0..3 of the step's group,
             // one component each, from the four waves' ballots (wave w holds rows 2w, 2w+1 of the tile: low / high 32 bits)
             const int j = tid >> 5, l = tid & 31;
@@ -1757,7 +1765,7 @@ __global__ __launch_bounds__(256) void k_superpose_uniform(const float* __restri
                     d0[0] = (preOkA && rowIn) ? va[i] : 0.0f;
                     if (lane + 64 < nC) d0[64] = (preOkB && rowIn) ? vb[i] : 0.0f;
                 }
-                __syncthreads();                                     // chunk and weights visible; the other buffer's readers are past it
+                ldsBarrier();                                        // chunk and weights visible; the other buffer's readers are past it
                 if (r0 + 32 < H) fetchChunk(a, r0 + 32); else if (a + 1 < nA) fetchChunk(a + 1, 0);
                 // this wave's block of the chunk (row half rb, column half cb), two chains over alternate k steps
                 f32x4 d0 = {0.0f, 0.0f, 0.0f, 0.0f}, d1 = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -1777,7 +1785,7 @@ __global__ __launch_bounds__(256) void k_superpose_uniform(const float* __restri
                 }
                 bufSel ^= 1;
             }
-            __syncthreads();
+            ldsBarrier();
             // ---- y pass: out[y] = sum_u w[u] tmp[y - 32 - rho + u] (tmp row y sits at 64 + y): blocks wv, wv + 4, ... of the strip ----
             {
                 const float* aw = &sWp[16 + kq - li];
@@ -1791,7 +1799,7 @@ __global__ __launch_bounds__(256) void k_superpose_uniform(const float* __restri
                         if (q < nQ) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bRow[(size_t)q * 32 * kUniTmpPitch], acc[q], 0, 0, 0);
                 }
             }
-            __syncthreads();                                         // this layer's weights and x-pass result are consumed
+            ldsBarrier();                                            // this layer's weights and x-pass result are consumed
         }
         float* out = bevDose + (size_t)k * fc.bevW * fc.bevH;
 #pragma unroll
