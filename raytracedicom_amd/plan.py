@@ -1,10 +1,11 @@
-"""Multi-GPU plan execution: fields shard one-per-rank, per-rank dose volumes are summed into rank 0.
+"""Multi-GPU plan execution over torch.distributed (one process per GPU): fields shard one per rank.
 
-The reference has no multi-GPU code (its beam loop, src/kernel_wrapper.cu:601, accumulates every beam into one
-device dose volume, :92). Beams are independent until that accumulation, so a plan shards by field with no
-data-path exchange except ONE float32 sum-reduce of the dose volume (RCCL over xGMI when the tensors live on
-GPUs; gloo in the CPU tests). Sum order differs from the sequential reference by float rounding only.
-"""
+The reference has no multi-GPU code (its beam loop, src/kernel_wrapper.cu:601, accumulates every beam into one device dose
+volume, :92). Beams are independent until that accumulation. What bench.py --gpus N uses is the LAST part of this module,
+`BevExchange` + `balanced_slabs`: the ranks all-gather their packed beam's-eye-view slabs (~10 MB each) and every rank writes its
+slab of the dose volume with all fields in field order — no dose data crosses xGMI, the volume is bit-identical to the one-GPU
+loop and stays sharded by slabs. The first part (`reduce_dose`, `PipelinedBoxReduce`, `PipelinedSlabReduce`: dose boxes summed into
+rank 0, round 1's exchange) is kept with its gloo tests, unused by the bench."""
 
 
 def shard_fields(n_fields, world_size, rank):
