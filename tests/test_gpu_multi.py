@@ -364,3 +364,32 @@ def test_deferred_ct_uploads_only_what_the_rays_cross(engine, synth, angles):
             got = base.copy()
             pl.compute(scn.beams, got)
         np.testing.assert_array_equal(got, want)
+
+
+def test_bench_line_keeps_the_contract():
+    """bench.py (small CT, few steps): ONE JSON line with every key of the driver's contract, the roofline and cpu_baseline objects, the
+    self-checks true and the parity leg green."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--size", "128", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in r, k
+    assert r["n_gpus"] == 1 and r["steps"] == 3 and r["warmup"] == 1 and r["higher_is_better"] is True and r["vs_baseline"] is None
+    assert r["dtype"] == "f32" and r["data"] == "synthetic" and "workload" in r["config"] and "model" not in r["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r["roofline"], k
+    assert abs(r["roofline"]["frac"] - r["roofline"]["achieved"] / r["roofline"]["peak"]) < 1e-3
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in r["cpu_baseline"], k
+    assert r["cpu_baseline"]["kind"] in ("port", "reference") and r["cpu_baseline"]["value"] > 0
+    assert r["clear_check"] is True and r["parity"]["gamma_1pct_1mm_pass"] == 1.0 and r["parity"]["max_rel_diff_above_10pct"] < 1e-4
+    assert r["ms_plan_end_to_end"]["matches_resident_path"] is True
