@@ -1,0 +1,35 @@
+"""Random sweep of water fields on a GPU box (not collected by pytest): the device-side uniform-sigma detection and the separable
+superposition kernel (k_superpose_uniform) through tests/test_gpu_parity._compare_field — every intermediate, the BEV dose, the dose
+and gamma against the CPU oracle — for seeded random water cubes (size, spots, pitch, layers, steps, homogeneous density); the field
+must report uniform_sigma = 1 when the beam is parallel, 0 when it diverges. Usage: FIRST_SEED END_SEED."""
+import os, sys, math
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+torch.zeros(1, device="cuda")
+from oracle import oracle as orc
+from raytracedicom_amd import engine, luts, scenarios
+import test_gpu_parity as T
+orc.lib(); orc.set_threads(16)
+synth = luts.synth_luts()
+n_ok = n_uni = 0
+for seed in range(int(sys.argv[1]), int(sys.argv[2])):
+    rng = np.random.default_rng(11000 + seed)
+    n = int(rng.choice([48, 64, 96, 128]))
+    spots = int(rng.integers(2, 20)); pitch = float(rng.choice([2.5, 3.0, 4.0, 6.0]))
+    n_layers = int(rng.choice([1, 2, 3, 7, 12, 20])); steps = int(rng.choice([200, 256, 400, 512]))
+    diverge = rng.random() < 0.25
+    dist = (float(rng.uniform(900, 3000)), float(rng.uniform(900, 3000))) if diverge else (math.inf, math.inf)
+    scn = scenarios.water_cube(synth, n=n, n_layers=n_layers, spots=spots, pitch=pitch, seed=int(rng.integers(1, 9999)), source_dist=dist, steps=steps)
+    scn.ct[:] = float(rng.choice([1000.0, 1000.0, 900.0, 1150.0]))       # homogeneous, not necessarily water
+    try:
+        dose, ref, timing, info = T._compare_field(orc, engine, scn, scn.beams[0])
+    except AssertionError as e:
+        if "(1.0, 0, 0.0)" in str(e):
+            print("seed", seed, "gamma had no voxels to evaluate (all other comparisons passed)"); n_ok += 1; continue
+        raise
+    assert info["uniform_sigma"] == (0 if diverge else 1), (seed, info["uniform_sigma"], diverge)
+    n_uni += info["uniform_sigma"]
+    n_ok += 1
+    print("seed", seed, "ok", n, spots, pitch, n_layers, steps, "diverging" if diverge else "parallel", "uniform" if info["uniform_sigma"] else "general", flush=True)
+print("all", n_ok, "ok;", n_uni, "through the uniform path")
