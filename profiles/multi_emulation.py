@@ -2,7 +2,7 @@
 """One-GPU emulation of what ONE rank of `bench.py --gpus N` does per plan step, for every rank in turn: its own field up to the
 BEV dose, pack, the all-gather replaced by device copies of the other ranks' (pre-exported) messages into the receive buffer, then
 every field transferred into the rank's slab, pipelined by one plan like bench.py. Everything but the xGMI traffic and RCCL's own
-kernels. Predicted N-GPU value = N * voxels / max over ranks of the step time. Usage: multi_emulation.py N [steps] [balanced 0|1] [fused transfer 0|1]
+kernels. Predicted N-GPU value = N * voxels / max over ranks of the step time. Usage: multi_emulation.py N [steps] [balanced 0|1] [fused transfer 0|1] [CT edge 512|768]
 -> one JSON line (profiles/r02_multi_emulation_*.json)."""
 import json
 import os
@@ -44,7 +44,7 @@ def main():
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     balanced = (int(sys.argv[3]) if len(sys.argv) > 3 else 1) != 0
     fused = (int(sys.argv[4]) if len(sys.argv) > 4 else 1) != 0
-    n = 512
+    n = int(sys.argv[5]) if len(sys.argv) > 5 else 512
     dev = torch.device("cuda", 0)
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
@@ -81,7 +81,7 @@ def main():
         messages.append(msg)
         f.destroy()
     doses[0].zero_()
-    out = {"n_gpus_emulated": world, "balanced": balanced, "fused_transfer": fused, "steps": steps, "ranks": []}
+    out = {"n_gpus_emulated": world, "ct_edge": n, "balanced": balanced, "fused_transfer": fused, "steps": steps, "ranks": []}
     for rank in range(world):
         flds = [eng.create_field(scn.beams[rank], scn.dims) for _ in range(3)]
         remote = {r: eng.create_field(scn.beams[r], scn.dims, remote=True) for r in range(world) if r != rank}
