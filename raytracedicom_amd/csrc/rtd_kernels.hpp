@@ -1970,9 +1970,37 @@ struct MultiFields {
     int n;
 };
 
+// What a brick needs to know of a field, gathered once per block (thread f reads field f's state record: one memory round trip for
+// all fields instead of one per (brick, field) — with ~1 brick per block and 8 fields that latency was comparable to the sampling).
+struct MultiParam {
+    int valid, slabZ;
+    int box0[3], box1[3];
+    TransferParams tp;
+    int pW, pH;
+    float pX0, pY0, exLo, exHi, eyLo, eyHi;
+    unsigned int slabOff;                                             // floats from the slab pointer to its first slice
+};
+static_assert(sizeof(MultiParam) % 4 == 0, "MultiParam is copied word by word");
+
 __global__ __launch_bounds__(256, 6) void k_transfer_multi(float* __restrict__ dose, int nx, int ny, int nz, MultiFields mf, ClipBox box) {
     __shared__ float accT[16][256];                                   // [z][thread]: a thread's 16 sums (private column: no barriers needed)
     __shared__ float tile[4][16][17];
+    __shared__ MultiParam sPar[kMultiMaxFields];
+    if ((int)threadIdx.x < mf.n) {
+        const FieldState* st = mf.st[threadIdx.x];
+        MultiParam q;
+        const int first = st->beamFirstInside;
+        q.slabZ = st->firstCalculatedPassive - first;
+        q.valid = (q.slabZ > 0 && !st->errorFlags) ? 1 : 0;           // as k_transfer: otherwise the field deposits nothing
+        // the field's own dose box, cut to the written box: the voxels of a partial brick beyond it are neither sampled nor written
+        for (int a = 0; a < 3; ++a) { q.box0[a] = st->tboxMin[a]; q.box1[a] = min(st->tboxMax[a], box.hi[a]); }
+        q.tp = st->transfer;
+        q.pW = st->packW; q.pH = st->packH; q.pX0 = (float)st->packX0; q.pY0 = (float)st->packY0;
+        q.exLo = (float)(st->bevLo[0] - 1); q.exHi = (float)(st->bevHi[0] + 1); q.eyLo = (float)(st->bevLo[1] - 1); q.eyHi = (float)(st->bevHi[1] + 1);
+        q.slabOff = (unsigned int)st->slabFirst * (unsigned int)q.pW * (unsigned int)q.pH;
+        sPar[threadIdx.x] = q;
+    }
+    __syncthreads();
     const int nbx = (box.hi[0] - box.lo[0]) / 16 + 1, nby = (box.hi[1] - box.lo[1]) / 16 + 1, nbz = (box.hi[2] - box.lo[2]) / 16 + 1;
     const int nBricks = nbx * nby * nbz;
     const int tid = threadIdx.x;
@@ -1984,20 +2012,23 @@ __global__ __launch_bounds__(256, 6) void k_transfer_multi(float* __restrict__ d
 #pragma unroll
         for (int z = 0; z < 16; ++z) accT[z][tid] = 0.0f;
         for (int fi = 0; fi < mf.n; ++fi) {
-            const FieldState* st = mf.st[fi];
-            const int first = st->beamFirstInside;
-            const int slabZ = st->firstCalculatedPassive - first;
-            if (slabZ <= 0 || st->errorFlags) continue;               // (uniform) as k_transfer: such a field deposits nothing
-            // the field's own dose box: voxels outside it are not visited by its transfer
-            // (cut to the written box: the voxels of a partial brick beyond it are neither sampled nor written)
-            const int bx0 = st->tboxMin[0], by0 = st->tboxMin[1], bz0 = st->tboxMin[2];
-            const int bx1 = min(st->tboxMax[0], box.hi[0]), by1 = min(st->tboxMax[1], box.hi[1]), bz1 = min(st->tboxMax[2], box.hi[2]);
+            // the field's record from LDS into scalar registers (the values are block-uniform)
+            MultiParam q;
+            {
+                const int* src = reinterpret_cast<const int*>(&sPar[fi]);
+                int* dst = reinterpret_cast<int*>(&q);
+#pragma unroll
+                for (int w = 0; w < (int)(sizeof(MultiParam) / 4); ++w) dst[w] = __builtin_amdgcn_readfirstlane(src[w]);
+            }
+            if (!q.valid) continue;                                   // (uniform)
+            const int slabZ = q.slabZ;
+            const int bx0 = q.box0[0], by0 = q.box0[1], bz0 = q.box0[2], bx1 = q.box1[0], by1 = q.box1[1], bz1 = q.box1[2];
             if (x0 > bx1 || x0 + 15 < bx0 || y0 > by1 || y0 + 15 < by0 || z0 > bz1 || z0 + 15 < bz0) continue;   // (uniform)
-            const TransferParams p0 = st->transfer;
-            const int pW = st->packW, pH = st->packH;
-            const float pX0 = (float)st->packX0, pY0 = (float)st->packY0;
-            const float* slab = mf.bev[fi] + (size_t)st->slabFirst * pW * pH;
-            const float exLo = (float)(st->bevLo[0] - 1), exHi = (float)(st->bevHi[0] + 1), eyLo = (float)(st->bevLo[1] - 1), eyHi = (float)(st->bevHi[1] + 1);
+            const TransferParams p0 = q.tp;
+            const int pW = q.pW, pH = q.pH;
+            const float pX0 = q.pX0, pY0 = q.pY0;
+            const float* slab = mf.bev[fi] + q.slabOff;
+            const float exLo = q.exLo, exHi = q.exHi, eyLo = q.eyLo, eyHi = q.eyHi;
             auto sampleAt = [&](const Vec3& pos) -> float {
                 if (pos.x > exLo && pos.x < exHi && pos.y > eyLo && pos.y < eyHi)
                     return sample3dBorder(slab, pW, pH, slabZ, pos.x - pX0, pos.y - pY0, pos.z);
