@@ -735,10 +735,12 @@ static void stage_superposition(const float* idd, const float* rs, float* bev, i
  * slab dims (W+64, H+64, calcPassive-first) with BORDER addressing (kernel_wrapper.cu:1107-1141). */
 static void stage_transfer(float* dose, const unsigned int doseDims[3], const transfer_params* tp0, const int minIdx[3],
                            const int maxIdx[3], const float* slab, int sx, int sy, int sz) {
+    /* The launch (kernel_wrapper.cu:1209-1210) rounds the grid up to whole 32 x 8 blocks in x AND y; the extra threads are masked
+     * only by x < doseDims.x && y < doseDims.y (:80), so both axes run past maxIdx up to the block edge; z stops at maxIdx.z. */
+    const int yEnd = minIdx[1] + ((maxIdx[1] - minIdx[1] + 1 + 7) / 8) * 8;
 #pragma omp parallel for schedule(static)
-    for (int y = minIdx[1]; y <= maxIdx[1]; ++y) {
+    for (int y = minIdx[1]; y < yEnd; ++y) {
         if (y < 0 || y >= (int)doseDims[1]) continue;
-        /* grid is rounded up to 32 in x (kernel_wrapper.cu:1210); extra threads are masked by x < doseDims.x */
         int xEnd = minIdx[0] + ((maxIdx[0] - minIdx[0] + 1 + 31) / 32) * 32;
         for (int x = minIdx[0]; x < xEnd; ++x) {
             if (x < 0 || x >= (int)doseDims[0]) continue;

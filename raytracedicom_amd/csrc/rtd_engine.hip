@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -62,14 +63,19 @@ struct rtd_handle_impl {
     size_t ctOwnedVoxels = 0;     // size of dCtOwned: a CT of the same size is uploaded in place (no free + malloc of the volume)
     uint32_t ctDims[3] = {0, 0, 0};
     const float* ctHost = nullptr;                 // rtd_set_ct_deferred: the caller's volume, uploaded box by box as fields need it
-    std::vector<std::array<int, 6>> ctBoxes;       // boxes of ctHost already on the device (x0, y0, z0, x1, y1, z1 inclusive)
+    struct CtBox { std::array<int, 6> box; hipEvent_t done; hipStream_t stream; };
+    std::vector<CtBox> ctBoxes;                    // boxes of ctHost already on the device (x0, y0, z0, x1, y1, z1 inclusive), each with the
+                                                   // event of its upload and the stream it was issued on (a consumer on another stream waits for it)
+    void clearCtBoxes() { for (auto& b : ctBoxes) if (b.done) (void)hipEventDestroy(b.done); ctBoxes.clear(); }
 };
 
 // what the device allocations of a field depend on: a released workspace is reused by a field with the same signature
+// (W and H separately, not only R = W * H: the padded BEV cube is (W + 64) x (H + 64) x S and the superposition's hand-off slots and
+//  node counters scale with ceil(bevW / 64) * ceil(bevH / 32) — a 64 x 32 and a 32 x 64 ray grid need different sizes)
 struct AllocSig {
-    size_t R = 0, S = 0, L = 0, nSpot = 0, nInterm = 0, G = 0, tileRadWords = 0;
+    size_t W = 0, H = 0, S = 0, L = 0, nSpot = 0, nInterm = 0, G = 0, tileRadWords = 0;
     bool operator==(const AllocSig& o) const {
-        return R == o.R && S == o.S && L == o.L && nSpot == o.nSpot && nInterm == o.nInterm && G == o.G && tileRadWords == o.tileRadWords;
+        return W == o.W && H == o.H && S == o.S && L == o.L && nSpot == o.nSpot && nInterm == o.nInterm && G == o.G && tileRadWords == o.tileRadWords;
     }
 };
 
@@ -99,6 +105,8 @@ struct rtd_field_impl {
     bool uniformEligible = false; // the separable superposition may take the field (no nuclear halo, BEV height within its accumulators)
     int uniformHint = -1;         // what the last finished compute found: 0 heterogeneous, 1 one sigma per slice, -1 unknown
     unsigned hintEpoch = 0;       // ... under this handle->inputEpoch
+    unsigned launchEpoch = 0;     // handle->inputEpoch when the compute in flight was launched (what its findings are valid for)
+    bool launchedKnownUniform = false;   // the compute in flight skipped the general superposition kernel on the strength of the hint
     bool triedUniform = false;    // the compute in flight ran the detection
     // NUCLEAR_CORR (default off): the halo on the spot-resolution grid
     int* dNucSpotIdx = nullptr; float *dNucRayWeights = nullptr, *dNucIdd = nullptr, *dNucRs = nullptr, *dNucBev = nullptr;
@@ -227,6 +235,7 @@ int rtd_destroy(rtd_handle hh) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     while (!h->fieldCache.empty()) { rtd_field_impl* c = h->fieldCache.back(); h->fieldCache.pop_back(); rtd_field_destroy(hh, reinterpret_cast<rtd_field>(c)); }
+    h->clearCtBoxes();
     if (h->dLutBlock) (void)hipFree(h->dLutBlock);
     if (h->dCtOwned) (void)hipFree(h->dCtOwned);
     if (h->ownStream) (void)hipStreamDestroy(h->ownStream);
@@ -414,9 +423,10 @@ int rtd_set_ct_device(rtd_handle hh, const float* dev, const uint32_t dims[3]) {
     if (h) ++h->inputEpoch;
     if (!h || !dev || !dims || !dims[0] || !dims[1] || !dims[2]) return RTD_ERR_INVALID_ARG;
     RTD_HIP(h, hipSetDevice(h->device));
-    if (h->dCtOwned) { RTD_HIP(h, hipStreamSynchronize(h->stream)); RTD_HIP(h, hipFree(h->dCtOwned)); h->dCtOwned = nullptr; h->ctOwnedVoxels = 0; }
+    // (device-wide: the handle may have had kernels on other streams, rtd_set_stream, that still read the volume)
+    if (h->dCtOwned) { RTD_HIP(h, hipDeviceSynchronize()); RTD_HIP(h, hipFree(h->dCtOwned)); h->dCtOwned = nullptr; h->ctOwnedVoxels = 0; }
     h->dCt = dev;
-    h->ctHost = nullptr; h->ctBoxes.clear();
+    h->ctHost = nullptr; h->clearCtBoxes();
     std::memcpy(h->ctDims, dims, sizeof h->ctDims);
     return RTD_OK;
 }
@@ -427,12 +437,12 @@ int rtd_set_ct(rtd_handle hh, const float* host, const uint32_t dims[3]) {   // 
     if (!h || !host || !dims || !dims[0] || !dims[1] || !dims[2]) return RTD_ERR_INVALID_ARG;
     RTD_HIP(h, hipSetDevice(h->device));
     const size_t n = (size_t)dims[0] * dims[1] * dims[2];
-    RTD_HIP(h, hipStreamSynchronize(h->stream));                     // no kernel still reads the volume that is replaced
+    RTD_HIP(h, hipDeviceSynchronize());                              // no kernel, on any stream the handle has used, still reads the volume that is replaced
     if (h->dCtOwned && h->ctOwnedVoxels != n) { RTD_HIP(h, hipFree(h->dCtOwned)); h->dCtOwned = nullptr; }
     if (!h->dCtOwned) { RTD_HIP(h, hipMalloc((void**)&h->dCtOwned, n * sizeof(float))); h->ctOwnedVoxels = n; }
     RTD_HIP(h, hipMemcpy(h->dCtOwned, host, n * sizeof(float), hipMemcpyHostToDevice));
     h->dCt = h->dCtOwned;
-    h->ctHost = nullptr; h->ctBoxes.clear();
+    h->ctHost = nullptr; h->clearCtBoxes();
     std::memcpy(h->ctDims, dims, sizeof h->ctDims);
     return RTD_OK;
 }
@@ -445,11 +455,11 @@ int rtd_set_ct_deferred(rtd_handle hh, const float* host, const uint32_t dims[3]
     if (!h || !host || !dims || !dims[0] || !dims[1] || !dims[2]) return RTD_ERR_INVALID_ARG;
     RTD_HIP(h, hipSetDevice(h->device));
     const size_t n = (size_t)dims[0] * dims[1] * dims[2];
-    RTD_HIP(h, hipStreamSynchronize(h->stream));
+    RTD_HIP(h, hipDeviceSynchronize());
     if (h->dCtOwned && h->ctOwnedVoxels != n) { RTD_HIP(h, hipFree(h->dCtOwned)); h->dCtOwned = nullptr; }
     if (!h->dCtOwned) { RTD_HIP(h, hipMalloc((void**)&h->dCtOwned, n * sizeof(float))); h->ctOwnedVoxels = n; }
     h->dCt = h->dCtOwned;
-    h->ctHost = host; h->ctBoxes.clear();
+    h->ctHost = host; h->clearCtBoxes();
     std::memcpy(h->ctDims, dims, sizeof h->ctDims);
     return RTD_OK;
 }
@@ -603,7 +613,7 @@ static int createField(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dim
     const size_t R = f->R, P = (size_t)fc.bevW * fc.bevH;
     const size_t nSpot = (size_t)b->spot_nx * b->spot_ny * L;
     f->tileRadWords = ((size_t)L * S * tilesX * tilesY + 3) / 4;      // filled as 32-bit words by k_reset
-    f->sig.R = R; f->sig.S = (size_t)S; f->sig.L = (size_t)L; f->sig.nSpot = nSpot; f->sig.nInterm = (size_t)W * b->spot_ny * L;
+    f->sig.W = (size_t)W; f->sig.H = (size_t)H; f->sig.S = (size_t)S; f->sig.L = (size_t)L; f->sig.nSpot = nSpot; f->sig.nInterm = (size_t)W * b->spot_ny * L;
     f->sig.G = (size_t)f->ksGroups; f->sig.tileRadWords = f->tileRadWords;
     rtd_field_impl* husk = nullptr;
     for (size_t i = 0; i < h->fieldCache.size(); ++i)
@@ -713,8 +723,14 @@ static int ensureCtBox(rtd_handle_impl* h, rtd_field_impl* f) {
         box[3 + d] = (int)std::min(b, (double)h->ctDims[d] - 1.0);
         if (box[3 + d] < box[d]) return RTD_OK;                       // the beam misses the volume: every sample is BORDER zero
     }
-    for (const auto& u : h->ctBoxes)
-        if (u[0] <= box[0] && u[1] <= box[1] && u[2] <= box[2] && u[3] >= box[3] && u[4] >= box[4] && u[5] >= box[5]) return RTD_OK;
+    for (const auto& cb : h->ctBoxes) {
+        const auto& u = cb.box;
+        if (u[0] <= box[0] && u[1] <= box[1] && u[2] <= box[2] && u[3] >= box[3] && u[4] >= box[4] && u[5] >= box[5]) {
+            // uploaded on another stream (rtd_set_stream in between): this field's tracer is ordered behind that copy
+            if (cb.stream != h->stream) RTD_HIP(h, hipStreamWaitEvent(h->stream, cb.done, 0));
+            return RTD_OK;
+        }
+    }
     const size_t nx = h->ctDims[0], ny = h->ctDims[1];
     int x0 = box[0], x1 = box[3];
     if ((size_t)(x1 - x0 + 1) * 2 >= nx) { x0 = 0; x1 = (int)nx - 1; box[0] = x0; box[3] = x1; }   // wide boxes travel as whole rows
@@ -726,7 +742,10 @@ static int ensureCtBox(rtd_handle_impl* h, rtd_field_impl* f) {
     p.extent = make_hipExtent((size_t)(x1 - x0 + 1) * sizeof(float), (size_t)(box[4] - box[1] + 1), (size_t)(box[5] - box[2] + 1));
     p.kind = hipMemcpyHostToDevice;
     RTD_HIP(h, hipMemcpy3DAsync(&p, h->stream));
-    h->ctBoxes.push_back(box);
+    rtd_handle_impl::CtBox cb{box, nullptr, h->stream};
+    RTD_HIP(h, hipEventCreateWithFlags(&cb.done, hipEventDisableTiming));
+    h->ctBoxes.push_back(cb);
+    RTD_HIP(h, hipEventRecord(cb.done, h->stream));
     return RTD_OK;
 }
 
@@ -741,9 +760,11 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
     // the uniform-sigma detection and kernel are skipped for a field that was found heterogeneous under the same CT / LUTs / options
     const bool tryUniform = f->uniformEligible && !(f->uniformHint == 0 && f->hintEpoch == h->inputEpoch);
     f->triedUniform = tryUniform;
+    f->launchEpoch = h->inputEpoch;
     // ... and a field that was found uniform under the same inputs will be found uniform again (the test is exact arithmetic on
     // the same values): the general superposition kernel, all of whose ~10^5 blocks would only look at the flag and leave, is not launched
     const bool knownUniform = tryUniform && f->uniformHint == 1 && f->hintEpoch == h->inputEpoch;
+    f->launchedKnownUniform = knownUniform;
     const FieldConst& fc = f->fc;
     hipStream_t s = h->stream;
     const bool timing = h->opt.fine_grained_timing != 0;
@@ -1008,7 +1029,10 @@ int rtd_field_wait_plan(rtd_handle hh, rtd_field ff, rtd_field_info* info, size_
     RTD_HIP(h, hipSetDevice(h->device));
     RTD_HIP(h, hipEventSynchronize(f->ev[4]));
     const FieldState st = *f->hState;                                // mirrored by k_ks_plan into pinned host memory
-    if (f->triedUniform) { f->uniformHint = st.uniformField ? 1 : 0; f->hintEpoch = h->inputEpoch; }
+    // (the finding belongs to the inputs the compute was LAUNCHED under: CT, LUTs or options may have changed since)
+    if (f->triedUniform) { f->uniformHint = st.uniformField ? 1 : 0; f->hintEpoch = f->launchEpoch; }
+    if (f->launchedKnownUniform && !st.uniformField && !st.errorFlags && !st.empty)
+        return fail(h, RTD_ERR_NOT_READY, "the field was launched as a uniform-sigma field but is not one: its inputs were modified in place; call rtd_set_ct* again and recompute");
     if (info) fillInfo(f, st, info);
     if (packed_bytes) {
         const int nz = std::max(st.firstCalculatedPassive - st.beamFirstInside, 0);
@@ -1077,7 +1101,11 @@ int rtd_field_finish(rtd_handle hh, rtd_field ff, rtd_timing* timing, rtd_field_
     const int last = f->transferred ? 6 : 5;                         // BEV only: the superposition's reduce is the last kernel
     RTD_HIP(h, hipEventSynchronize(f->ev[last]));
     const FieldState st = *f->hState;                                // mirrored by k_ks_plan into pinned host memory
-    if (f->triedUniform) { f->uniformHint = st.uniformField ? 1 : 0; f->hintEpoch = h->inputEpoch; }
+    if (f->triedUniform) { f->uniformHint = st.uniformField ? 1 : 0; f->hintEpoch = f->launchEpoch; }
+    // A compute that skipped the general kernel (hint: uniform) on a field the device then found heterogeneous has written no BEV
+    // dose: only possible when the caller changed a bound device volume in place (rtd_set_ct_device) without telling the handle.
+    if (f->launchedKnownUniform && !st.uniformField && !st.errorFlags && !st.empty)
+        return fail(h, RTD_ERR_NOT_READY, "the field was launched as a uniform-sigma field but is not one: its inputs were modified in place; call rtd_set_ct* again and recompute");
     if (timing) {
         std::memset(timing, 0, sizeof *timing);
         RTD_HIP(h, hipEventElapsedTime(&timing->total_ms, f->ev[0], f->ev[last]));

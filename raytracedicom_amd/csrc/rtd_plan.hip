@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
@@ -235,15 +236,20 @@ int rtd_plan_compute(rtd_plan_t p, const rtd_beam* beams, int n_beams, float* do
     std::vector<size_t> msgBytes((size_t)n_beams, 0);
     std::vector<void*> msgPtr((size_t)n_beams, nullptr);
     std::vector<int> boxLo((size_t)n_beams * 3, 0), boxHi((size_t)n_beams * 3, -1);   // the beams' dose boxes (from their owners)
-    std::vector<int> failed((size_t)D, 0);
-    auto anyFailed = [&] { for (int v : failed) if (v) return true; return false; };
+    std::vector<std::atomic<int>> failed((size_t)D);
+    for (auto& v : failed) v.store(0);
+    auto anyFailed = [&] { for (auto& v : failed) if (v.load()) return true; return false; };
+    // One answer for all device threads: the flags are read between two barriers, where nobody writes them. Whether the threads go
+    // on to a step in which they depend on each other (the exchange: a thread that skips or leaves an ncclBroadcast sequence its
+    // peers are inside of leaves them blocked forever) is decided with this, never with a thread's own view.
+    auto agreeOk = [&] { bar.wait(); const bool ok = !anyFailed(); bar.wait(); return ok; };
 
     auto worker = [&](int d) {
         DevSlot& s = p->dev[(size_t)d];
         s.status = RTD_OK; s.error.clear();
         for (float& m : s.ms) m = 0.0f;
-        auto bad = [&](int st) { if (st != RTD_OK && s.status == RTD_OK) { s.status = st; s.error = rtd_last_error(s.h); failed[(size_t)d] = 1; } return st != RTD_OK; };
-        auto badHip = [&](hipError_t e) { if (e != hipSuccess && s.status == RTD_OK) { s.status = RTD_ERR_HIP; s.error = std::string("HIP error: ") + hipGetErrorString(e); failed[(size_t)d] = 1; } return e != hipSuccess; };
+        auto bad = [&](int st) { if (st != RTD_OK && s.status == RTD_OK) { s.status = st; s.error = rtd_last_error(s.h); failed[(size_t)d].store(1); } return st != RTD_OK; };
+        auto badHip = [&](hipError_t e) { if (e != hipSuccess && s.status == RTD_OK) { s.status = RTD_ERR_HIP; s.error = std::string("HIP error: ") + hipGetErrorString(e); failed[(size_t)d].store(1); } return e != hipSuccess; };
         (void)hipSetDevice(s.device);
         hipStream_t stream = (hipStream_t)rtd_stream(s.h);
         // ---- 1. this device's z-slab of the volume (allocation only: what travels is decided after step 2) ----
@@ -285,7 +291,7 @@ int rtd_plan_compute(rtd_plan_t p, const rtd_beam* beams, int n_beams, float* do
         }
         if (s.status == RTD_OK && (D > 1 || (p->useRccl && p->selfMessages))) bad(rtd_sync(s.h));   // the messages are complete before they travel
         s.ms[1] = (float)(nowMs() - t);
-        bar.wait();
+        const bool bevOk = agreeOk();                                 // (also: boxes, message sizes and pointers of all beams are published)
 
         // ---- 1b. upload the block of the slab that the plan can change: bounding box of all beams' dose boxes, cut to the slab ----
         t = nowMs();
@@ -298,7 +304,7 @@ int rtd_plan_compute(rtd_plan_t p, const rtd_beam* beams, int n_beams, float* do
         blkLo[2] = std::max(blkLo[2], z0); blkHi[2] = std::min(blkHi[2], z1);
         const bool haveBlock = slabN && blkHi[0] >= blkLo[0] && blkHi[1] >= blkLo[1] && blkHi[2] >= blkLo[2];
         // on the copy stream, so that it runs beside the superposition kernels still in flight; the transfers wait for its event
-        if (!anyFailed() && haveBlock && s.status == RTD_OK) {
+        if (bevOk && haveBlock) {
             if (!badHip(copyBox(true, dose_inout, s.dSlab, dose_dims, z0, blkLo, blkHi, s.copyStream)) && !badHip(hipEventRecord(s.uploaded, s.copyStream)))
                 badHip(hipStreamWaitEvent(stream, s.uploaded, 0));
         }
@@ -308,8 +314,11 @@ int rtd_plan_compute(rtd_plan_t p, const rtd_beam* beams, int n_beams, float* do
         t = nowMs();
         std::vector<const void*> slabOf((size_t)n_beams, nullptr);
         std::vector<rtd_field> theirs((size_t)n_beams, nullptr);
+        std::vector<int> inSlot((size_t)n_beams, -1);
         const bool viaMessage = p->useRccl && p->selfMessages;         // owners read the exchanged copy too
-        if (!anyFailed() && (D > 1 || viaMessage)) {
+        const bool exchange = D > 1 || viaMessage;
+        // 3a. every receive buffer is allocated BEFORE the first collective, then the threads agree: all enter the exchange or none
+        if (bevOk && exchange) {
             size_t in = 0;
             for (int i = 0; i < n_beams && s.status == RTD_OK; ++i) {
                 const int owner = i % D;
@@ -323,22 +332,34 @@ int rtd_plan_compute(rtd_plan_t p, const rtd_beam* beams, int n_beams, float* do
                     if (bad(rtd_device_alloc(s.h, msgBytes[(size_t)i], &s.msgIn[in]))) break;
                     s.msgInCap[in] = msgBytes[(size_t)i];
                 }
-                if (p->useRccl) {
-                    // every device makes the call for every beam, in beam order: root = the device that computed it
-                    const ncclResult_t r = p->rccl.broadcast(owner == d ? msgPtr[(size_t)i] : s.msgIn[in], s.msgIn[in], msgBytes[(size_t)i], ncclUint8, owner,
-                                                             p->comms[(size_t)d], s.copyStream);
-                    if (r != ncclSuccess) { if (s.status == RTD_OK) { s.status = RTD_ERR_HIP; s.error = std::string("RCCL: ") + p->rccl.errorString(r); failed[(size_t)d] = 1; } break; }
-                } else if (badHip(hipMemcpyPeerAsync(s.msgIn[in], s.device, msgPtr[(size_t)i], o.device, msgBytes[(size_t)i], s.copyStream))) break;
-                slabOf[(size_t)i] = s.msgIn[in];
+                inSlot[(size_t)i] = (int)in;
                 ++in;
             }
-            if (s.status == RTD_OK) badHip(hipStreamSynchronize(s.copyStream));
+        }
+        const bool exchangeOk = agreeOk() && bevOk;
+        // 3b. the exchange itself; with RCCL no thread leaves the sequence of broadcasts early (an error is recorded, the calls go on)
+        if (exchangeOk && exchange) {
+            for (int i = 0; i < n_beams; ++i) {
+                const int in = inSlot[(size_t)i];
+                if (in < 0) continue;
+                const int owner = i % D;
+                const DevSlot& o = p->dev[(size_t)owner];
+                if (p->useRccl) {
+                    // every device makes the call for every beam, in beam order: root = the device that computed it
+                    const ncclResult_t r = p->rccl.broadcast(owner == d ? msgPtr[(size_t)i] : s.msgIn[(size_t)in], s.msgIn[(size_t)in], msgBytes[(size_t)i], ncclUint8, owner,
+                                                             p->comms[(size_t)d], s.copyStream);
+                    if (r != ncclSuccess && s.status == RTD_OK) { s.status = RTD_ERR_HIP; s.error = std::string("RCCL: ") + p->rccl.errorString(r); failed[(size_t)d].store(1); }
+                } else if (s.status == RTD_OK) badHip(hipMemcpyPeerAsync(s.msgIn[(size_t)in], s.device, msgPtr[(size_t)i], o.device, msgBytes[(size_t)i], s.copyStream));
+                slabOf[(size_t)i] = s.msgIn[(size_t)in];
+            }
+            badHip(hipStreamSynchronize(s.copyStream));
         }
         s.ms[2] = (float)(nowMs() - t);
 
         // ---- 4. transfers of ALL beams into this device's slab, in beam order (= the reference's `+=` order) ----
         t = nowMs();
-        if (!anyFailed() && slabN) {
+        const bool transferOk = agreeOk() && exchangeOk;
+        if (transferOk && slabN) {
             for (int i = 0; i < n_beams && s.status == RTD_OK; ++i) {
                 if (i % D == d && !viaMessage) { bad(rtd_field_transfer(s.h, mine[(size_t)i], doseBase, clipLo, clipHi)); continue; }
                 if (bad(rtd_field_create_remote(s.h, &beams[i], dose_dims, &theirs[(size_t)i]))) break;
@@ -351,11 +372,11 @@ int rtd_plan_compute(rtd_plan_t p, const rtd_beam* beams, int n_beams, float* do
             if (mine[(size_t)i] && s.status == RTD_OK) bad(rtd_field_finish(s.h, mine[(size_t)i], per_beam ? &per_beam[i] : nullptr, nullptr));
         if (s.status == RTD_OK) bad(rtd_sync(s.h));
         s.ms[3] = (float)(nowMs() - t);
-        bar.wait();                                                    // nobody frees a message another device still reads
+        const bool allOk = agreeOk();                                 // (also: nobody frees a message another device still reads)
 
         // ---- 5. download this device's slab (:1318) — only when every device succeeded: the volume is all-or-nothing ----
         t = nowMs();
-        if (!anyFailed() && haveBlock) {
+        if (allOk && haveBlock) {
             if (!badHip(copyBox(false, dose_inout, s.dSlab, dose_dims, z0, blkLo, blkHi, stream)))
                 badHip(hipStreamSynchronize(stream));
         }

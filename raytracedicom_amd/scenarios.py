@@ -130,10 +130,11 @@ def make_field(luts, n, voxel, origin, gantry_deg, spots, pitch, n_layers, seed,
                steps=512, ray_spacing=(1.0, 1.0), start_z=128.0, step_len=1.0, weight_lo=90.0, weight_span=10.0, gantry_rot=None):
     """gantry_rot: a 3x3 gantry -> world rotation replacing the rotation about the world Y axis by gantry_deg."""
     gantryToImIdx = _geometry(n, voxel, origin, gantry_deg, gantry_rot)
-    off = -0.5 * (spots - 1) * pitch
-    spotIdxToGantry = Float3IdxTransform((pitch, pitch, -step_len), (off, off, start_z))
+    nx, ny = (spots, spots) if np.isscalar(spots) else (int(spots[0]), int(spots[1]))     # a pair: (columns, rows) of the spot map
+    px, py = (pitch, pitch) if np.isscalar(pitch) else (float(pitch[0]), float(pitch[1]))
+    spotIdxToGantry = Float3IdxTransform((px, py, -step_len), (-0.5 * (nx - 1) * px, -0.5 * (ny - 1) * py, start_z))
     rng = np.random.default_rng(seed)
-    weights = (weight_lo + weight_span * rng.random((n_layers, spots, spots))).astype(np.float32)
+    weights = (weight_lo + weight_span * rng.random((n_layers, ny, nx))).astype(np.float32)
     energies, sigmas = water_cube_energies(luts, n_layers)
     return BeamSettings(weights, energies, sigmas, ray_spacing, steps, source_dist, spotIdxToGantry, gantryToImIdx,
                         gantryToImIdx)
@@ -190,5 +191,6 @@ def hetero_ct(luts, n=512, n_fields=1, spots=10, pitch=6.0, n_layers=20, seed=99
         angles = [i * 360.0 / n_fields for i in range(n_fields)]
     beams = [make_field(luts, n, voxel, origin, a, spots, pitch, n_layers, seed + 17 * i, source_dist, steps, gantry_rot=gantry_rot)
              for i, a in enumerate(angles)]
+    snx, sny = (spots, spots) if np.isscalar(spots) else spots
     return Scenario("hetero%d_F%d" % (n, len(beams)), luts, ct, (voxel,) * 3, beams,
-                    "heterogeneous CT %d^3, %d field(s), %dx%dx%d spots" % (n, len(beams), spots, spots, n_layers))
+                    "heterogeneous CT %d^3, %d field(s), %dx%dx%d spots" % (n, len(beams), snx, sny, n_layers))

@@ -300,6 +300,76 @@ def test_released_workspace_is_taken_over(engine, synth):
         eng.device_free(d)
 
 
+def test_released_workspace_is_not_taken_over_by_a_transposed_ray_grid(engine, synth):
+    """Two beams with the same number of rays, steps, layers and spots but transposed ray grids (64 x 32 against 32 x 64) need
+    different workspaces: the padded BEV cube is (W + 64) x (H + 64) x S and the superposition's hand-off slots / node counters
+    scale with ceil(bevW / 64) * ceil(bevH / 32) (6 against 8 output tiles here). A released workspace must only go to a field of
+    the same W AND H; the result of the second beam equals a fresh engine's bit for bit."""
+    ct, _ = scenarios.hetero_phantom(64)
+
+    def beam_of(spots, pitch):
+        return scenarios.hetero_ct(synth, n=64, spots=spots, pitch=pitch, n_layers=2, angles=[0.0], steps=160, ct=ct, seed=5).beams[0]
+    # 4 x 1 spots at 9 mm -> 64 x 32 rays; 2 x 2 spots at (1, 27) mm -> 32 x 64 rays: same ray count, spot count, intermediate size
+    a, b = beam_of((4, 1), 9.0), beam_of((2, 2), (1.0, 27.0))
+    scn = scenarios.hetero_ct(synth, n=64, spots=2, pitch=4.0, n_layers=2, angles=[0.0], steps=160, ct=ct)
+    n = scn.n_voxels
+    want = _sequential(engine, scenarios.Scenario("b", synth, ct, scn.spacing, [b]))
+    with engine.Engine(0) as eng:
+        eng.set_luts(synth)
+        eng.set_ct(ct)
+        d = eng.device_alloc(4 * n)
+        fa = eng.create_field(a, scn.dims)
+        eng.device_zero(d, 4 * n)
+        fa.compute(d)
+        _, ia = fa.finish()
+        fa.release()
+        fb = eng.create_field(b, scn.dims)
+        eng.device_zero(d, 4 * n)
+        fb.compute(d)
+        _, ib = fb.finish()
+        assert ia["ray_dims"][:2] == [64, 32] and ib["ray_dims"][:2] == [32, 64], (ia["ray_dims"], ib["ray_dims"])
+        out = np.empty_like(ct)
+        eng.to_host(out, d)
+        np.testing.assert_array_equal(out, want)
+        fb.release()
+        eng.device_free(d)
+
+
+def test_uniform_hint_belongs_to_the_inputs_of_the_launch(orc, engine, synth):
+    """compute (water) -> set_ct (heterogeneous) -> finish -> compute: what the first compute learned (one sigma per slice) is
+    recorded for the CT it was LAUNCHED under, not for the one bound when the host got round to finishing it; the second compute
+    must run the general superposition and give the heterogeneous field's dose."""
+    scn = scenarios.water_cube(synth, n=96, n_layers=2, spots=9, pitch=5.0)
+    ct2 = scn.ct.copy()
+    ct2[:, :, : ct2.shape[2] // 2] *= 1.3
+    scn2 = scenarios.Scenario("water with a density step", scn.luts, ct2, scn.spacing, scn.beams)
+    want2 = _sequential(engine, scn2)
+    n = scn.n_voxels
+    with engine.Engine(0) as eng:
+        eng.set_luts(scn.luts)
+        eng.set_ct(scn.ct)
+        d = eng.device_alloc(4 * n)
+        fld = eng.create_field(scn.beams[0], scn.dims)
+        eng.device_zero(d, 4 * n)
+        fld.compute(d)
+        _, info = fld.finish()
+        assert info["uniform_sigma"] == 1                            # the hint is now "uniform" under the water CT
+        eng.device_zero(d, 4 * n)
+        fld.compute(d)                                               # launched as a known-uniform field
+        eng.set_ct(ct2)                                              # ... the CT changes before the host finishes it
+        _, info = fld.finish()
+        assert info["uniform_sigma"] == 1
+        eng.device_zero(d, 4 * n)
+        fld.compute(d)
+        _, info = fld.finish()
+        assert info["uniform_sigma"] == 0
+        out = np.empty_like(scn.ct)
+        eng.to_host(out, d)
+        np.testing.assert_array_equal(out, want2)
+        fld.destroy()
+        eng.device_free(d)
+
+
 def test_in_process_plan_over_rccl_transport(orc, engine, synth, monkeypatch):
     """RTD_PLAN_TRANSPORT=rccl: the slabs travel by ncclBroadcast on communicators made with ncclCommInitAll (librccl opened on demand).
     One GPU allows one rank only; RTD_PLAN_SELF_MESSAGES makes the owner transfer from the broadcast copy, so export -> RCCL ->

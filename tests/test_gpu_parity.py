@@ -149,9 +149,9 @@ def test_c4_four_field_plan_sum(orc, engine, synth, ct512):
     assert rate == 1.0 and n_eval > 1000000, (rate, n_eval, gmax)
 
 
-@pytest.mark.parametrize("idx", [0, 1, 2, 5])
+@pytest.mark.parametrize("idx", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_c5_hetero_768_fields(orc, engine, synth, ct768, idx):
-    """BASELINE.json configs[4]: 768^3 CT (voxel 1/3 mm), fields of the eight-angle plan at 0, 45, 90 and 225 degrees."""
+    """BASELINE.json configs[4]: 768^3 CT (voxel 1/3 mm), every field of the eight-angle plan (0, 45, ..., 315 degrees)."""
     scn = scenarios.hetero_ct(synth, n=768, n_fields=8, ct=ct768)
     _compare_field(orc, engine, scn, scn.beams[idx])
 
@@ -193,6 +193,38 @@ def test_beam_axes_other_than_rotation_about_y(orc, engine, synth, rot, steps):
     scn = scenarios.hetero_ct(synth, n=96, spots=5, pitch=7.0, n_layers=3, angles=[0.0], source_dist=(1500.0, 2100.0), steps=steps, ct=ct,
                               gantry_rot=rot)
     _compare_field(orc, engine, scn, scn.beams[0])
+
+
+@pytest.mark.parametrize("dist", [(math.inf, math.inf), (1400.0, 1900.0)])
+def test_beam_along_dose_y_fine_voxels(orc, engine, synth, dist):
+    """The BEV depth axis maps to dose y (gantry z = world +y: the beam travels towards -y) on voxels finer than the step
+    (384^3 on the 256 mm cube: 2/3 mm voxels, 1 mm steps). The reference's transfer launch rounds its grid up to whole 32 x 8 blocks
+    and masks by the dose dimensions only (kernel_wrapper.cu:1209-1210, guard :80), so y, like x, runs past maxIdx.y up to the block
+    edge; here that edge lies in front of the entry slice, where the BEV value one voxel beyond maxIdx.y still interpolates against
+    the first slice. Engine and oracle must both deposit there (the oracle stopped at maxIdx.y until round 3)."""
+    n = 384
+    ct, voxel = scenarios.hetero_phantom(n)
+    rot = ((1, 0, 0), (0, 0, 1), (0, -1, 0))                          # gantry x -> world x, y -> -z, z -> +y
+    # the beam starts INSIDE the volume (world y = 60.633 mm = voxel 282.95), so that rows past maxIdx.y = 283 exist, and voxel
+    # 284 lies 0.7 steps in front of the entry slice: the launch's over-run rows receive ~12 % of the maximum dose
+    beam = scenarios.make_field(synth, n, voxel, (-128.0, -128.0, -106.0), 0.0, 5, 7.0, 3, 11, dist, 300, start_z=60.633, gantry_rot=rot)
+    scn = scenarios.Scenario("beam along -y", synth, ct, (voxel,) * 3, [beam])
+    dose, ref, timing, info = _compare_field(orc, engine, scn, scn.beams[0])
+    ymax = info["bbox_max"][1]
+    cov = min(info["bbox_min"][1] + ((ymax - info["bbox_min"][1] + 1 + 7) // 8) * 8 - 1, scn.dims[1] - 1)
+    assert cov > ymax                                                 # the launch does run past maxIdx.y in this geometry
+    over = ref[:, ymax + 1:cov + 1, :]                                # [z][y][x]
+    assert over.max() > 0.05 * ref.max(), "the rows past maxIdx.y carry no dose: the case is not exercised"
+    np.testing.assert_array_equal(dose[:, ymax + 1:cov + 1, :] > 0, over > 0)
+
+
+def test_spot_map_taller_than_the_lds_tile(orc, engine, synth):
+    """A spot map of 400 rows (> kConvMaxRows = 384): the spot -> ray convolution runs as the two launches k_conv_x / k_conv_y through
+    the intermediate buffer instead of the fused k_conv (gpu_convolution_2d.cu:16-59 is two launches as well); ray weights bit-exact."""
+    ct, _ = scenarios.hetero_phantom(64)
+    scn = scenarios.hetero_ct(synth, n=64, spots=(3, 400), pitch=0.6, n_layers=2, angles=[0.0], steps=120, ct=ct)
+    _, _, _, info = _compare_field(orc, engine, scn, scn.beams[0])
+    assert info["ray_dims"][1] >= 240
 
 
 def test_wide_field_many_tiles(orc, engine, synth):
