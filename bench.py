@@ -20,6 +20,7 @@ Also reported: `ms_plan_latency` (ONE plan, nothing to pipeline against) and, at
 
 Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--size 512] [--no-cpu]
        N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+            or plain `python bench.py --gpus N ...`, which starts exactly that launcher as a child process and relays its output
 """
 import argparse
 import json
@@ -94,14 +95,26 @@ def main():
     ap.add_argument("--backend", default="nccl", help="process-group backend; 'gloo' only to rehearse N>1 on a one-GPU box")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as a CHILD process (this process has made no
+    # GPU call yet and never will: it only relays the child's output — rank 0's JSON line — and exit code).
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+
     import torch
     from raytracedicom_amd import abi, engine, luts, plan, scenarios
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" % (args.gpus, args.gpus))
+    if args.gpus != world:
+        raise SystemExit("bench.py --gpus %d started with WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the dose engine has no CPU fallback")
     xchg = world > 1 or args.exchange_selftest          # the N>1 path (a world of one rank only with --exchange-selftest)
@@ -212,7 +225,10 @@ def main():
         if ex is not None and i not in completed:
             ex.complete(f, i % 2, doses[i % 2].data_ptr())
         completed.discard(i)
-        return f.finish()
+        r = f.finish()
+        if ex is not None:
+            ex.check(f)                 # the plan still fits what setup() froze (message capacity, dose box)
+        return r
 
     def step():
         """One plan iteration in steady state. N=1: launch plan i, then finish plan i-1 — its last kernel sits in front of plan i's in
@@ -351,6 +367,32 @@ def main():
         dist.all_reduce(slab_sum, op=dist.ReduceOp.SUM)
         dist.all_reduce(field_sum, op=dist.ReduceOp.SUM)
         reduce_check = abs(float(slab_sum.item()) - float(field_sum.item())) / max(float(field_sum.item()), 1e-300)
+    # (c) N>1: the plan's volume ASSEMBLED on rank 0 — every rank's volume is zero outside its slab, so a sum over the ranks
+    #     (x + 0 = x exactly) is the gather of the slabs — against the reference's sequential beam loop on one GPU
+    #     (kernel_wrapper.cu:601, `+=` at :92): all fields accumulated into one zeroed volume in field order. Bit for bit.
+    assembled_check = None
+    if xchg:
+        if args.backend == "nccl":
+            dist.reduce(last, dst=0, op=dist.ReduceOp.SUM)
+            assembled = last
+        else:
+            host_part = last.cpu()
+            dist.reduce(host_part, dst=0, op=dist.ReduceOp.SUM)
+            assembled = host_part.to(dev) if rank == 0 else None
+        if rank == 0:
+            ref.zero_()
+            for r in range(world):
+                fr = flds[0] if r == rank else eng.create_field(scn.beams[r], scn.dims)
+                fr.compute(ref.data_ptr())
+                fr.finish()
+                if r != rank:
+                    fr.destroy()
+            torch.cuda.synchronize()
+            assembled_check = bool(torch.equal(assembled, ref))
+        # the headers of the messages this rank received carry the senders' device-side error flags: none may be set
+        for f_r in ex.remote.values():
+            f_r.finish()
+        last.zero_()
     del ref
 
     if rank == 0:
@@ -388,7 +430,7 @@ def main():
             if valu_per_launch and pmc.get("simd_cycles_per_launch"):
                 roof["issue_cycle_frac"] = round((4.0 * valu_per_launch + 32.0 * mfma_per_launch) / pmc["simd_cycles_per_launch"], 3)
         result = {
-            "metric": "Mvoxels/s dose deposited (%d^3 CT, 1 field per GPU)" % n,
+            "metric": "Mvoxels/s dose deposited (%d^3 CT, 1 field per GPU), inputs resident in HBM" % n,
             "value": round(world * n_vox / elapsed * args.steps / 1e6, 3),
             "unit": "Mvoxels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -409,7 +451,7 @@ def main():
             "ms_plan": round(ms_per_step, 4),
             "ms_plan_latency": round(ms_latency, 4),
             "throughput_3_streams": multi,
-            "reduce_check_rel_err": reduce_check, "clear_check": clear_check,
+            "reduce_check_rel_err": reduce_check, "clear_check": clear_check, "assembled_check": assembled_check,
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "algorithmic_bytes": alg,
             "path_gbs": round(alg["total"] / (stage_ms["total_ms"] * 1e-3) / 1e9, 2),
@@ -478,6 +520,8 @@ def main():
             result["cpu_baseline"] = {
                 "value": round(n_cpu_fields * n_vox / cpu_s / 1e6, 3), "unit": "Mvoxels/s", "cores": ncpu, "kind": "port",
                 "cpu_model": cpu_model(),
+                "cores_note": "threads used = %d; this process may use %d of the host's logical CPUs (the GPU box's container share, not the whole socket)"
+                              % (ncpu, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)),
                 "sample": "%d fields of the same workload (the N=1 field + gantry 90/180/270), CPU oracle (oracle/rtd_oracle.c) "
                           "with %d OpenMP threads: %.1f s wall = %.0f CPU-s; first field alone %.2f s"
                           % (n_cpu_fields, ncpu, cpu_s, cpu_s * ncpu, cpu_first),
@@ -525,6 +569,8 @@ def main():
                            "(as the reference's per-beam cudaMallocs do), second_call reuses them. Round-2 start, whole volumes both ways: 30 ms"
                            % (ct_host.nbytes // 10 ** 6, dose_host.nbytes // 10 ** 6))
             result["ms_plan_end_to_end"] = e2e
+            # the metric on the REFERENCE'S timed span (uploads + kernels + download); `value` above is the resident-data rate
+            result["value_reference_span_mvoxels_s"] = round(n_vox / (e2e["second_call"]["ms"] * 1e-3) / 1e6, 1)
         print(json.dumps(result))
     for f in flds:
         f.destroy()

@@ -98,8 +98,9 @@ class _StandInField:
         nx, ny, nz = self.dims
         vol = np.ctypeslib.as_array(ctypes.cast(dose_ptr, ctypes.POINTER(ctypes.c_float)), shape=(nz, ny, nx))
         b, blk = self._block()
-        q = plan.box_intersection(b, list(lo) + list(hi))
-        if q is None:
+        c = list(lo) + list(hi)
+        q = [max(b[i], c[i]) for i in range(3)] + [min(b[3 + i], c[3 + i]) for i in range(3)]
+        if any(q[3 + i] < q[i] for i in range(3)):
             return
         dst = vol[q[2]:q[5] + 1, q[1]:q[4] + 1, q[0]:q[3] + 1]
         src = blk[q[2] - b[2]:q[5] - b[2] + 1, q[1] - b[1]:q[4] - b[1] + 1, q[0] - b[0]:q[3] - b[0] + 1]
@@ -152,6 +153,11 @@ def _worker(rank, world, port, out_dir):
         pending = b
     ex.complete(own, pending, vols[pending].data_ptr())
     assert torch.equal(vols[0], vols[1])
+    ex.check(own)                                                     # the plans still fit what setup() froze ...
+    grown = _StandInField(scn.dims, mine, [max(box[0] - 1, 0)] + box[1:])
+    if grown.box != box:
+        with pytest.raises(RuntimeError):                            # ... a field whose dose box has grown does not
+            ex.check(grown)
     lo, hi = ex.clip()
     out = vols[0].numpy()
     mask = np.zeros_like(out, dtype=bool)

@@ -408,6 +408,29 @@ def test_bench_exchange_path_under_rccl_with_one_rank():
     assert "all-gather" in r["config"]["exchange"] and r["value"] > 0
 
 
+def test_bench_launches_its_own_ranks_two_processes_one_gpu():
+    """`python bench.py --gpus 2` with no launcher in front: bench.py starts torch.distributed.run as a child process before it
+    touches the GPU and relays rank 0's line. Two ranks share this box's one GPU over gloo (the RCCL world needs one GPU per rank):
+    the N>1 path with two real ranks — two slabs gathered, each rank writing its slab with both fields. The slabs together hold the
+    sum of the fields (reduce_check), a reused volume is clean (clear_check), and the volume assembled on rank 0 equals the
+    sequential beam loop of the reference (kernel_wrapper.cu:601, :92) bit for bit (assembled_check)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--size", "128", "--steps", "4",
+                        "--warmup", "2", "--no-cpu"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 4 and r["scaling"] == "weak"
+    assert r["reduce_check_rel_err"] < 1e-9 and r["clear_check"] is True and r["assembled_check"] is True
+    assert r["value"] > 0 and "all-gather" in r["config"]["exchange"]
+
+
 @pytest.mark.parametrize("angles", [(0.0,), (90.0, 37.0, 200.0)])
 def test_deferred_ct_uploads_only_what_the_rays_cross(engine, synth, angles):
     """rtd_set_ct_deferred / rtd_plan_set_ct_deferred: every field uploads the index box of the CT its tracer can sample. The device

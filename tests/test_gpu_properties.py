@@ -161,156 +161,6 @@ def test_clear_dose_resets_exactly_the_written_box(engine, synth):
     eng.close()
 
 
-def test_pipelined_exchange_queues_destination_adds_on_a_side_stream():
-    """plan.PipelinedBoxReduce under RCCL (destination rank): the adds of the received boxes are queued on a side stream at submit
-    and retired by an event wait. Exercised on one GPU with a stand-in process group whose receives deliver known boxes."""
-    import torch
-    from raytracedicom_amd import plan
-
-    class Work:
-        def wait(self):
-            return True
-
-    class FakeDist:
-        P2POp = staticmethod(lambda op, tensor, peer: (op, tensor, peer))
-        isend, irecv = "isend", "irecv"
-
-        def get_rank(self): return 0
-        def get_world_size(self): return 3
-        def get_backend(self): return "nccl"
-
-        def all_gather(self, out, mine):
-            boxes = [[2, 3, 4, 9, 8, 7], [0, 0, 0, 5, 5, 5], [6, 6, 6, 5, 5, 5]]     # rank 2 wrote nothing (max < min)
-            for o, b in zip(out, boxes):
-                o.copy_(torch.tensor(b, dtype=o.dtype))
-
-        def batch_isend_irecv(self, ops):
-            for op, tensor, peer in ops:
-                assert op == "irecv" and peer == 1
-                tensor.fill_(float(peer) + 0.5)
-            return [Work()]                                           # coalesced, as RCCL returns it
-
-    dev = torch.device("cuda:0")
-    red = plan.PipelinedBoxReduce(FakeDist(), dst=0, static_boxes=True)
-    vols = [torch.zeros((12, 12, 12), device=dev) for _ in range(2)]
-    for it in range(4):
-        v = vols[it % 2]
-        views = red.release(v)
-        if it >= 2:
-            assert views is not None and len(views) == 1
-            torch.cuda.synchronize()
-            ref = torch.zeros_like(v)
-            ref[4:8, 3:9, 2:10] = 1.0                                  # own field
-            ref[0:6, 0:6, 0:6] += 1.5                                  # + the box received from rank 1
-            assert torch.equal(v, ref)
-            v[4:8, 3:9, 2:10] = 0.0
-            for w in views:
-                w.zero_()
-            assert not bool(v.any())
-        v[4:8, 3:9, 2:10] += 1.0                                       # "compute" this rank's field into its box
-        ready = torch.cuda.Event()
-        ready.record(torch.cuda.current_stream())
-        other = vols[(it + 1) % 2]
-        other.mul_(1.0)                                                # later work on the main stream must not delay the exchange
-        red.submit(v, (2, 3, 4), (9, 8, 7), ready=ready if it % 2 else None)
-    red.drain()
-    torch.cuda.synchronize()
-    assert float(vols[1][0, 0, 0]) == 1.5 and float(vols[1][5, 5, 5]) == 2.5 and red.side is not None
-
-
-def test_slab_reduce_between_three_ranks_on_one_gpu():
-    """plan.PipelinedSlabReduce, RCCL branch (everything queued on a side stream at submit, retired by an event wait), between three
-    ranks played by three threads on one GPU: a stand-in process group moves the packed tensors through mailboxes in stream
-    order. Rank 0 must end with the sum of the three fields; on every rank, clearing the own box plus the returned views must
-    restore the zero volume (bench.py's dirty-box clearing)."""
-    import queue
-    import threading
-    import torch
-    from raytracedicom_amd import plan
-
-    world, n = 3, 20
-    boxes = [[2, 3, 1, 13, 12, 17], [0, 5, 6, 18, 10, 11], [6, 0, 4, 9, 19, 15]]       # (x0, y0, z0, x1, y1, z1), overlapping
-    mail = {(s, r): queue.Queue() for s in range(world) for r in range(world)}
-    dev = torch.device("cuda:0")
-
-    class Work:
-        def __init__(self, recvs): self.recvs = recvs
-        def wait(self):                                              # stream-ordered, like RCCL: the current stream waits for the data
-            for tensor, peer, me in self.recvs:
-                src, ev = mail[(peer, me)].get(timeout=60)
-                torch.cuda.current_stream().wait_event(ev)
-                tensor.copy_(src)
-            self.recvs = []
-            return True
-
-    class FakeDist:
-        isend, irecv = "isend", "irecv"
-        def __init__(self, rank): self.rank = rank
-        def P2POp(self, op, tensor, peer): return (op, tensor, peer)
-        def get_rank(self): return self.rank
-        def get_world_size(self): return world
-        def get_backend(self): return "nccl"
-        def all_gather(self, out, mine):
-            for o, b in zip(out, boxes):
-                o.copy_(torch.tensor(b, dtype=o.dtype))
-        def batch_isend_irecv(self, ops):
-            recvs = []
-            for op, tensor, peer in ops:
-                if op == "isend":
-                    ev = torch.cuda.Event()
-                    ev.record(torch.cuda.current_stream())
-                    mail[(self.rank, peer)].put((tensor, ev))
-                else:
-                    recvs.append((tensor, peer, self.rank))
-            return [Work(recvs)]                                      # coalesced, as RCCL returns it
-
-    expect = torch.zeros((n, n, n), device=dev)
-    for r, b in enumerate(boxes):
-        expect[b[2]:b[5] + 1, b[1]:b[4] + 1, b[0]:b[3] + 1] += float(r + 1)
-    errors, results = [], {}
-
-    def run(rank):
-        try:
-            with torch.cuda.stream(torch.cuda.Stream(device=dev)):
-                red = plan.PipelinedSlabReduce(FakeDist(rank), dst=0, static_boxes=True)
-                b = boxes[rank]
-                vols = [torch.zeros((n, n, n), device=dev) for _ in range(2)]
-                for it in range(4):
-                    v = vols[it % 2]
-                    views = red.release(v)
-                    if it >= 2:
-                        if rank == 0:
-                            torch.cuda.current_stream().synchronize()
-                            assert torch.equal(v, expect), "rank 0 does not hold the sum of the three fields"
-                        v[b[2]:b[5] + 1, b[1]:b[4] + 1, b[0]:b[3] + 1] = 0.0
-                        for w in views or ():
-                            w.zero_()
-                        assert not bool(v.any()), "own box + returned views do not cover what the exchange wrote"
-                    v[b[2]:b[5] + 1, b[1]:b[4] + 1, b[0]:b[3] + 1] += float(rank + 1)     # "compute" this rank's field
-                    ready = torch.cuda.Event()
-                    ready.record(torch.cuda.current_stream())
-                    red.submit(v, b[:3], b[3:], ready=ready if it % 2 else None)
-                red.drain()
-                torch.cuda.current_stream().synchronize()
-                results[rank] = (vols[0].clone(), red.side is not None)
-        except Exception as e:                                        # noqa: BLE001 - reported by the main thread
-            errors.append((rank, repr(e)))
-
-    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join(timeout=120)
-    assert not errors, errors
-    assert all(not t.is_alive() for t in threads)
-    assert torch.equal(results[0][0], expect) and all(results[r][1] for r in range(world))
-    axis, slabs = plan.slab_partition(boxes, world)
-    for r in (1, 2):                                                  # an owner holds the complete sum inside its slab
-        sl = slabs[r]
-        assert torch.equal(results[r][0][sl[2]:sl[5] + 1, sl[1]:sl[4] + 1, sl[0]:sl[3] + 1],
-                           expect[sl[2]:sl[5] + 1, sl[1]:sl[4] + 1, sl[0]:sl[3] + 1])
-
-
 def test_field_launch_sequence_is_hipgraph_capturable(engine, synth):
     """rtd_field_clear_dose + rtd_field_compute make no host round trip, allocation or synchronisation, so the whole plan
     iteration can be captured into a hipGraph on the caller's stream; replays reproduce the directly launched dose bit for bit."""
