@@ -23,6 +23,7 @@
 #include "../../include/rtd.h"
 #include "rtd_geometry.hpp"
 #include "rtd_kernels.hpp"
+#include "rtd_sweep.hpp"
 
 using namespace rtd;
 
@@ -49,6 +50,7 @@ struct rtd_handle_impl {
     bool scanLdsSet = false;      // dynamic-LDS cap of k_trace_scan raised (once per handle)
     size_t traceTLds = 0;         // dynamic-LDS cap set for k_trace_sample_t so far
     size_t uniLds = 0;            // ... for k_superpose_uniform
+    bool sweepLdsSet = false;     // ... for k_superpose_sweep
     unsigned inputEpoch = 0;      // bumped whenever CT, LUTs or options change (fields re-test what they learned about their input)
     // LUTs
     bool haveLuts = false;
@@ -73,9 +75,10 @@ struct rtd_handle_impl {
 // (W and H separately, not only R = W * H: the padded BEV cube is (W + 64) x (H + 64) x S and the superposition's hand-off slots and
 //  node counters scale with ceil(bevW / 64) * ceil(bevH / 32) — a 64 x 32 and a 32 x 64 ray grid need different sizes)
 struct AllocSig {
-    size_t W = 0, H = 0, S = 0, L = 0, nSpot = 0, nInterm = 0, G = 0, tileRadWords = 0;
+    size_t W = 0, H = 0, S = 0, L = 0, nSpot = 0, nInterm = 0, G = 0, Gs = 0, tileRadWords = 0;
     bool operator==(const AllocSig& o) const {
-        return W == o.W && H == o.H && S == o.S && L == o.L && nSpot == o.nSpot && nInterm == o.nInterm && G == o.G && tileRadWords == o.tileRadWords;
+        return W == o.W && H == o.H && S == o.S && L == o.L && nSpot == o.nSpot && nInterm == o.nInterm && G == o.G && Gs == o.Gs &&
+               tileRadWords == o.tileRadWords;
     }
 };
 
@@ -116,6 +119,7 @@ struct rtd_field_impl {
     TransferParams transfer0Nuc{};
     int transferModeNuc = 0;
     long long* dFillDbg = nullptr; size_t fillDbgN = 0;   // RTD_FILL_DEBUG: per-block clock stamps of k_fill (diagnostics)
+    long long* dSweepDbg = nullptr; size_t sweepDbgN = 0; // RTD_SWEEP_DEBUG: per-block clock stamps of k_superpose_sweep (diagnostics)
     FieldState* dState = nullptr;
     FieldState* hState = nullptr;      // pinned host mirror of *dState (written by k_ks_plan), and its device-side address
     FieldState* dHostState = nullptr;
@@ -126,6 +130,11 @@ struct rtd_field_impl {
     bool remote = false;         // geometry only: the BEV slab comes from another GPU (rtd_field_attach_bev)
     const unsigned char* attached = nullptr;   // remote: the packed message [FieldState | slab]
     int ksGroups = 14;   // layer groups of the superposition (partial BEV buffers); RTD_KS_GROUPS overrides
+    // k_superpose_sweep (rtd_sweep.hpp): layer groups, patches of the ray grid, partial tiles [step][patch][group][96 x 96], arrival counters [step]
+    int swGroups = 4, swPX = 1, swPY = 1;
+    float* dSwSlots = nullptr; int* dSwCount = nullptr;
+    int radiusHint = -1;          // largest batch radius the last finished compute found (-1 unknown), under hintEpoch like uniformHint
+    bool sweepEnabled = true;     // RTD_NO_SWEEP: every field through k_superpose_mfma
 };
 
 #define RTD_HIP(h, call)                                                                         \
@@ -470,9 +479,9 @@ int rtd_field_destroy(rtd_handle hh, rtd_field ff) {
     if (!h || !f) return RTD_ERR_INVALID_ARG;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = { f->dSpotWeights, f->dConvInterm, f->dRayWeights, f->dDensity, f->dWepl, f->dRrl, f->dIdd, f->dRSigma, f->dBev, f->dBevPart, f->dNodeCount,
+    void* ptrs[] = { f->dSpotWeights, f->dConvInterm, f->dRayWeights, f->dDensity, f->dWepl, f->dRrl, f->dIdd, f->dRSigma, f->dBev, f->dBevPart, f->dNodeCount, f->dSwSlots, f->dSwCount,
                      f->dFirstInside, f->dFirstOutside, f->dFirstPassive, f->dWeplMin, f->dBlockWeplMin, f->dTileRad,
-                     f->dLayers, f->dState, f->dStepTab, f->dActive, f->dSigMin, f->dSigMax, f->dFillDbg,
+                     f->dLayers, f->dState, f->dStepTab, f->dActive, f->dSigMin, f->dSigMax, f->dFillDbg, f->dSweepDbg,
                      f->dNucSpotIdx, f->dNucRayWeights, f->dNucIdd, f->dNucRs, f->dNucBev, f->dNucEffT, f->dStateNuc };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (f->hState) (void)hipHostFree(f->hState);
@@ -615,13 +624,21 @@ static int createField(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dim
     f->tileRadWords = ((size_t)L * S * tilesX * tilesY + 3) / 4;      // filled as 32-bit words by k_reset
     f->sig.W = (size_t)W; f->sig.H = (size_t)H; f->sig.S = (size_t)S; f->sig.L = (size_t)L; f->sig.nSpot = nSpot; f->sig.nInterm = (size_t)W * b->spot_ny * L;
     f->sig.G = (size_t)f->ksGroups; f->sig.tileRadWords = f->tileRadWords;
+    // sweep: 4 layer groups unless told otherwise; at most 64 layers per group; partial tiles below ~2 GiB
+    f->sweepEnabled = std::getenv("RTD_NO_SWEEP") == nullptr;
+    if (const char* v = std::getenv("RTD_SW_GROUPS")) f->swGroups = std::atoi(v);
+    f->swGroups = std::max(std::max(1, (L + kSwMaxLay - 1) / kSwMaxLay), std::min(std::min(f->swGroups, kSwMaxGroups), L));
+    f->swPX = (W + kSwPatch - 1) / kSwPatch; f->swPY = (H + kSwPatch - 1) / kSwPatch;
+    while (f->swGroups > std::max(1, (L + kSwMaxLay - 1) / kSwMaxLay) &&
+           (size_t)S * f->swPX * f->swPY * f->swGroups * kSwSlot * sizeof(float) > ((size_t)2 << 30)) --f->swGroups;
+    f->sig.Gs = (size_t)f->swGroups;
     rtd_field_impl* husk = nullptr;
     for (size_t i = 0; i < h->fieldCache.size(); ++i)
         if (h->fieldCache[i]->sig == f->sig) { husk = h->fieldCache[i]; h->fieldCache.erase(h->fieldCache.begin() + (long)i); break; }
     if (husk) {
         f->dSpotWeights = husk->dSpotWeights; f->dConvInterm = husk->dConvInterm; f->dRayWeights = husk->dRayWeights;
         f->dDensity = husk->dDensity; f->dWepl = husk->dWepl; f->dRrl = husk->dRrl; f->dIdd = husk->dIdd; f->dRSigma = husk->dRSigma;
-        f->dBev = husk->dBev; f->dBevPart = husk->dBevPart; f->dNodeCount = husk->dNodeCount; f->dFirstInside = husk->dFirstInside; f->dFirstOutside = husk->dFirstOutside;
+        f->dBev = husk->dBev; f->dBevPart = husk->dBevPart; f->dNodeCount = husk->dNodeCount; f->dSwSlots = husk->dSwSlots; f->dSwCount = husk->dSwCount; f->dFirstInside = husk->dFirstInside; f->dFirstOutside = husk->dFirstOutside;
         f->dFirstPassive = husk->dFirstPassive; f->dWeplMin = husk->dWeplMin; f->dBlockWeplMin = husk->dBlockWeplMin; f->dTileRad = husk->dTileRad; f->dLayers = husk->dLayers;
         f->dState = husk->dState; f->dStepTab = husk->dStepTab; f->dActive = husk->dActive; f->dSigMin = husk->dSigMin; f->dSigMax = husk->dSigMax; f->hState = husk->hState; f->dHostState = husk->dHostState;
         for (int i = 0; i < 9; ++i) f->ev[i] = husk->ev[i];
@@ -635,6 +652,7 @@ static int createField(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dim
     const size_t nOutTiles = (size_t)((fc.bevW + kKsTileX - 1) / kKsTileX) * ((fc.bevH + kKsTileY - 1) / kKsTileY);
     A(&f->dBevPart, nOutTiles * kKsTileX * kKsTileY * S * f->ksGroups);
     A(&f->dNodeCount, nOutTiles * S * 32);
+    A(&f->dSwSlots, (size_t)S * f->swPX * f->swPY * f->swGroups * kSwSlot); A(&f->dSwCount, (size_t)S);
     A(&f->dFirstInside, R); A(&f->dFirstOutside, R); A(&f->dFirstPassive, R * L); A(&f->dWeplMin, (size_t)S); A(&f->dBlockWeplMin, (R / 64) * (size_t)S);
     A(&f->dTileRad, f->tileRadWords * 4); A(&f->dLayers, (size_t)L); A(&f->dState, (size_t)1); A(&f->dStepTab, (size_t)2 * S); A(&f->dActive, (size_t)4 * L * S); A(&f->dSigMin, (size_t)L * S); A(&f->dSigMax, (size_t)L * S);
     if (st != RTD_OK) { rtd_field_destroy(hh, reinterpret_cast<rtd_field>(f)); return st; }
@@ -691,6 +709,7 @@ static int createField(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dim
     //  outside hold stale values that nothing samples; a fresh buffer is cleared once so that a fetch of "bev" reads zeros there)
     if (fresh) e = hipMemset(f->dBev, 0, P * (size_t)S * sizeof(float));
     if (fresh && e == hipSuccess) e = hipMemset(f->dNodeCount, 0, nOutTiles * (size_t)S * 32 * sizeof(int));
+    if (fresh && e == hipSuccess) e = hipMemset(f->dSwCount, 0, (size_t)S * sizeof(int));
     if (e != hipSuccess) { h->error = std::string("HIP error (clearing the BEV buffer / node counters): ") + hipGetErrorString(e); rtd_field_destroy(hh, reinterpret_cast<rtd_field>(f)); return RTD_ERR_HIP; }
     *out = reinterpret_cast<rtd_field>(f);
     return RTD_OK;
@@ -836,7 +855,7 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
                                      f->nucIdxToDoseIdx, f->transfer0Nuc, (int)f->doseDims[0], (int)f->doseDims[1], (int)f->doseDims[2]);
     }
     launchK(k_ks_plan, dim3(1), dim3(256), 0, s, nullptr, f->ev[4], f->dState, f->dLayers, fc, f->rayIdxToDoseIdx, f->transfer0,
-                          (int)f->doseDims[0], (int)f->doseDims[1], (int)f->doseDims[2], f->ksGroups, f->dHostState, f->dStateNuc,
+                          (int)f->doseDims[0], (int)f->doseDims[1], (int)f->doseDims[2], f->ksGroups, f->swGroups, f->dHostState, f->dStateNuc,
                           (const unsigned int*)f->dSigMin, (const unsigned int*)f->dSigMax, tryUniform ? 1 : 0);
     if (fc.nuclearCorr) {
         const int nPix = (fc.nucW + 2 * kMaxSuperpR) * (fc.nucH + 2 * kMaxSuperpR);
@@ -857,7 +876,29 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
                 (const FieldState*)f->dState, fc, (const unsigned int*)f->dSigMin, (const float*)f->dStepTab, f->dBev);
         ksStart = nullptr;
     }
-    if (!knownUniform) {
+    // The general superposition is k_superpose_sweep when every batch radius of the field is within its reach (<= 16), else
+    // k_superpose_mfma. Which one is known on the device (FieldState::maxRadius, k_ks_plan): both are launched and one of them returns
+    // at once — until a finished compute has told the host, under the same CT / LUTs / options, which of the two it is.
+    const bool radiusKnown = f->radiusHint >= 0 && f->hintEpoch == h->inputEpoch;
+    const bool runSweep = !knownUniform && f->sweepEnabled && !(radiusKnown && f->radiusHint > kSwMaxR);
+    const bool runMfma = !knownUniform && !(f->sweepEnabled && radiusKnown && f->radiusHint <= kSwMaxR);
+    if (runSweep) {
+        constexpr size_t swLds = (size_t)kSwLdsWords * sizeof(float);
+        if (!h->sweepLdsSet) {
+            RTD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_superpose_sweep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)swLds));
+            h->sweepLdsSet = true;
+        }
+        if (!f->dSweepDbg && std::getenv("RTD_SWEEP_DEBUG")) {
+            f->sweepDbgN = (size_t)(8 + 4 * 16) * fc.S * f->swPX * f->swPY * f->swGroups;
+            RTD_HIP(h, hipMalloc((void**)&f->dSweepDbg, f->sweepDbgN * sizeof(long long)));
+            RTD_HIP(h, hipMemset(f->dSweepDbg, 0, f->sweepDbgN * sizeof(long long)));
+        }
+        launchK(k_superpose_sweep, dim3((unsigned)(fc.S * f->swPX * f->swPY * f->swGroups)), dim3(64 * kSwWaves), swLds, s, ksStart, runMfma ? nullptr : f->ev[5],
+                (const float*)f->dIdd, (const float*)f->dRSigma, (const unsigned char*)f->dTileRad, (const LayerPlan*)f->dLayers, (const FieldState*)f->dState, fc,
+                f->swGroups, f->swPX, f->swPY, (const int*)f->dActive, f->dSwSlots, f->dSwCount, f->dBev, f->dSweepDbg);
+        ksStart = nullptr;
+    }
+    if (runMfma) {
         const int nTX = (fc.bevW + kKsTileX - 1) / kKsTileX, nTY = (fc.bevH + kKsTileY - 1) / kKsTileY;
         const int G = f->ksGroups;
         const int nItems = fc.S * G * nTY * nTX;
@@ -866,7 +907,7 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
         auto launchKs = [&](auto kernel) {
             launchK(kernel, dim3(nItems), dim3(64 * split), 0, s, ksStart, f->ev[5], (const float*)f->dIdd, (const float*)f->dRSigma,
                     f->dBevPart, (const unsigned char*)f->dTileRad, (const LayerPlan*)f->dLayers, (const FieldState*)f->dState, fc, nTX, nTY, G,
-                    (const int*)f->dActive, f->dBev, f->dNodeCount);
+                    (const int*)f->dActive, f->dBev, f->dNodeCount, f->sweepEnabled ? kSwMaxR : -1);
         };
         if (split == 1) launchKs(k_superpose_mfma<1>); else if (split == 2) launchKs(k_superpose_mfma<2>); else launchKs(k_superpose_mfma<4>);
     }
@@ -1031,6 +1072,8 @@ int rtd_field_wait_plan(rtd_handle hh, rtd_field ff, rtd_field_info* info, size_
     const FieldState st = *f->hState;                                // mirrored by k_ks_plan into pinned host memory
     // (the finding belongs to the inputs the compute was LAUNCHED under: CT, LUTs or options may have changed since)
     if (f->triedUniform) { f->uniformHint = st.uniformField ? 1 : 0; f->hintEpoch = f->launchEpoch; }
+    else if (f->hintEpoch != f->launchEpoch) { f->uniformHint = -1; f->hintEpoch = f->launchEpoch; }
+    f->radiusHint = (st.errorFlags || st.empty) ? -1 : st.maxRadius;   // (valid under hintEpoch, like the uniform hint)
     if (f->launchedKnownUniform && !st.uniformField && !st.errorFlags && !st.empty)
         return fail(h, RTD_ERR_NOT_READY, "the field was launched as a uniform-sigma field but is not one: its inputs were modified in place; call rtd_set_ct* again and recompute");
     if (info) fillInfo(f, st, info);
@@ -1102,6 +1145,8 @@ int rtd_field_finish(rtd_handle hh, rtd_field ff, rtd_timing* timing, rtd_field_
     RTD_HIP(h, hipEventSynchronize(f->ev[last]));
     const FieldState st = *f->hState;                                // mirrored by k_ks_plan into pinned host memory
     if (f->triedUniform) { f->uniformHint = st.uniformField ? 1 : 0; f->hintEpoch = f->launchEpoch; }
+    else if (f->hintEpoch != f->launchEpoch) { f->uniformHint = -1; f->hintEpoch = f->launchEpoch; }
+    f->radiusHint = (st.errorFlags || st.empty) ? -1 : st.maxRadius;   // (valid under hintEpoch, like the uniform hint)
     // A compute that skipped the general kernel (hint: uniform) on a field the device then found heterogeneous has written no BEV
     // dose: only possible when the caller changed a bound device volume in place (rtd_set_ct_device) without telling the handle.
     if (f->launchedKnownUniform && !st.uniformField && !st.errorFlags && !st.empty)
@@ -1152,6 +1197,7 @@ int rtd_field_fetch(rtd_handle hh, rtd_field ff, const char* name, void* host_ou
     else if (nm == "tile_radius") { src = f->dTileRad; n = L * S * tiles; }
     else if (nm == "bev") { src = f->dBev; n = 4 * (size_t)fc.bevW * fc.bevH * S; }
     else if (nm == "fill_debug" && f->dFillDbg) { src = f->dFillDbg; n = f->fillDbgN * sizeof(long long); }
+    else if (nm == "sweep_debug" && f->dSweepDbg) { src = f->dSweepDbg; n = f->sweepDbgN * sizeof(long long); }
     else if (nm == "eff_radius" || nm == "layer_plan") {
         std::vector<LayerPlan> lp(L);
         RTD_HIP(h, hipMemcpy(lp.data(), f->dLayers, L * sizeof(LayerPlan), hipMemcpyDeviceToHost));

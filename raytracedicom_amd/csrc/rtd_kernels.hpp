@@ -58,6 +58,7 @@ struct FieldState {
     TransferParams transfer;        // :1213
     int empty;                      // nothing inside the patient for this beam
     int groupPassive[32];           // per superposition layer group: first step at which none of its layers deposits
+    int swGroupPassive[16];         // the same for the layer groups of k_superpose_sweep (rtd_sweep.hpp: its own, smaller group count)
     int actUnion[4];                // minima of (x, y, -x, -y) over all rays that carry dose in any (layer, step)
     int bevLo[2], bevHi[2];         // padded-BEV rectangle outside which every slice is exactly zero (transfer early-out)
     // The slab the transfer samples: packW x packH pixels per slice, pixel (0, 0) = padded-BEV pixel (packX0, packY0), first
@@ -1033,7 +1034,7 @@ __device__ inline void transferBoxes(const FromFan& rayIdxToDoseIdx, int W, int 
 // K6: superposition plan = host batching of radii (kernel_wrapper.cu:965-976) + beamFirstCalculatedPassive
 // (:955-957) + transfer bounding box and shift (:1185-1213), all on the device.
 __global__ __launch_bounds__(256) void k_ks_plan(FieldState* stGlobal, LayerPlan* layers, FieldConst fc, FromFan rayIdxToDoseIdx, TransferParams tp0,
-                                                 int doseNx, int doseNy, int doseNz, int G, FieldState* __restrict__ hostMirror,
+                                                 int doseNx, int doseNy, int doseNz, int G, int Gs, FieldState* __restrict__ hostMirror,
                                                  FieldState* __restrict__ stNuc, const unsigned int* __restrict__ sigMin,
                                                  const unsigned int* __restrict__ sigMax, int uniformEligible) {
     // The state record is completed in LDS and then written out — to device memory and to its pinned host mirror — by all threads,
@@ -1041,7 +1042,7 @@ __global__ __launch_bounds__(256) void k_ks_plan(FieldState* stGlobal, LayerPlan
     // store to it and a serial copy over PCIe by one thread cost microseconds each.
     __shared__ FieldState sSt;
     __shared__ int sMaxPassive;
-    __shared__ int sGroup[32];
+    __shared__ int sGroup[32], sGroupSw[16];
     __shared__ int sMaxRad;
     __shared__ unsigned long long sLive;
     __shared__ int sSliceDiffers;
@@ -1052,6 +1053,7 @@ __global__ __launch_bounds__(256) void k_ks_plan(FieldState* stGlobal, LayerPlan
     }
     if (threadIdx.x == 0) { sMaxPassive = 0; sMaxRad = 0; sLive = 0ull; sSliceDiffers = 0; }
     if (threadIdx.x < 32) sGroup[threadIdx.x] = 0;
+    if (threadIdx.x < 16) sGroupSw[threadIdx.x] = 0;
     __syncthreads();
     FieldState* st = &sSt;
     const int first = st->beamFirstInside;
@@ -1082,6 +1084,7 @@ __global__ __launch_bounds__(256) void k_ks_plan(FieldState* stGlobal, LayerPlan
         atomicMax(&sMaxRad, layerMax);
         atomicMax(&sMaxPassive, p.layerFirstPassive);
         atomicMax(&sGroup[l % G], p.layerFirstPassive);
+        atomicMax(&sGroupSw[l % Gs], p.layerFirstPassive);
         if (p.layerFirstPassive > first) atomicAdd(&sLive, (unsigned long long)(p.layerFirstPassive - first));
     }
     __syncthreads();
@@ -1143,6 +1146,7 @@ __global__ __launch_bounds__(256) void k_ks_plan(FieldState* stGlobal, LayerPlan
         st->uniformField = (maybeUniform && !sSliceDiffers) ? 1 : 0;
         st->maxRadius = sMaxRad;
         for (int gI = 0; gI < 32; ++gI) st->groupPassive[gI] = sGroup[gI];
+        for (int gI = 0; gI < 16; ++gI) st->swGroupPassive[gI] = sGroupSw[gI];
         st->bevLo[0] = bevLo[0]; st->bevLo[1] = bevLo[1]; st->bevHi[0] = bevHi[0]; st->bevHi[1] = bevHi[1];
         st->liveSteps = (long long)sLive;
         st->packX0 = 0; st->packY0 = 0; st->packW = fc.bevW; st->packH = fc.bevH; st->slabFirst = first;
@@ -1293,7 +1297,7 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
                                                             float* __restrict__ bevPart, const unsigned char* __restrict__ tileRad,
                                                             const LayerPlan* __restrict__ layers, const FieldState* __restrict__ st,
                                                             FieldConst fc, int nTX, int nTY, int G, const int* __restrict__ active,
-                                                            float* __restrict__ bevDose, int* __restrict__ nodeCount) {
+                                                            float* __restrict__ bevDose, int* __restrict__ nodeCount, int sweepMaxR) {
     constexpr int kSlice = kKsWaveLds + kKsReachTiles;
     static_assert(kKsSplit == 1 || kKsSplit * kSlice >= 2048, "the accumulator exchange needs 2048 floats of LDS");
     __shared__ __attribute__((aligned(16))) float ldsAll[kKsSplit * kSlice];
@@ -1316,6 +1320,7 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
     const int first = st->beamFirstInside, calcPassive = st->firstCalculatedPassive;
     if (st->errorFlags) return;                                      // radius overflow: the reference throws before any superposition (kernel_wrapper.cu:965)
     if (st->uniformField) return;                                    // one sigma per slice: k_superpose_uniform has written the BEV dose
+    if (st->maxRadius <= sweepMaxR) return;                          // every batch radius within k_superpose_sweep's reach: it writes the BEV dose
     if (k < 0 || k < first || k >= calcPassive) return;
     const int li = lane & 15, kq = lane >> 4;                         // MFMA 16x16x4: A[i=li][k=kq], B[k=kq][j=li]
     const int ox0 = tX * kKsTileX, oy0 = tY * kKsTileY;               // padded BEV coordinates of the owned tile
