@@ -628,7 +628,7 @@ static int createField(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dim
     f->sweepEnabled = std::getenv("RTD_NO_SWEEP") == nullptr;
     if (const char* v = std::getenv("RTD_SW_GROUPS")) f->swGroups = std::atoi(v);
     f->swGroups = std::max(std::max(1, (L + kSwMaxLay - 1) / kSwMaxLay), std::min(std::min(f->swGroups, kSwMaxGroups), L));
-    f->swPX = (W + kSwPatch - 1) / kSwPatch; f->swPY = (H + kSwPatch - 1) / kSwPatch;
+    f->swPX = (W + kSwPatch - 1) / kSwPatch; f->swPY = (H + kSwPatchRows - 1) / kSwPatchRows;
     while (f->swGroups > std::max(1, (L + kSwMaxLay - 1) / kSwMaxLay) &&
            (size_t)S * f->swPX * f->swPY * f->swGroups * kSwSlot * sizeof(float) > ((size_t)2 << 30)) --f->swGroups;
     f->sig.Gs = (size_t)f->swGroups;

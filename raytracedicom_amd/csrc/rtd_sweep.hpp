@@ -37,18 +37,20 @@
 namespace rtd {
 
 constexpr int kSwWaves = 8;                          // waves per block
-constexpr int kSwPatch = 64;                         // sources per patch edge (one lane per source of a row)
+constexpr int kSwPatch = 64;                         // source columns per patch (one lane per source of a row)
+constexpr int kSwPatchRows = 64;                     // source rows per patch
 constexpr int kSwMaxR = 16;                          // largest batch radius this kernel takes
 constexpr int kSwOut = kSwPatch + 2 * kSwMaxR;       // 96: edge of the output tile of a patch
+constexpr int kSwOutRows = kSwPatchRows + 2 * kSwMaxR;   // rows of the output tile
 constexpr int kSwNCB = kSwOut / 16;                  // 6 column blocks
 constexpr int kSwGuard = kSwMaxR + 1;                // table entry 17 is always zero: the lookups clamp to it
 constexpr int kSwTS = 19;                            // floats per source table (entries 0 .. 17 + pad; odd: the build's stores are conflict-free)
 constexpr int kSwPitch = 100;                        // row pitch of the tile in LDS: 4 rows = 400 floats = 16 banks on — the four row groups
                                                      // of a flush (rows 4 kq + r, columns li) fall into 64 different banks
-constexpr int kSwSlot = kSwOut * kSwOut;             // floats of a partial tile
+constexpr int kSwSlot = kSwOutRows * kSwOut;             // floats of a partial tile
 constexpr int kSwMaxLay = 64;                        // layers per group (one lane each when the list is made)
 constexpr int kSwMaxGroups = 16;
-constexpr int kSwTileRows = 9, kSwTileCols = 3;      // 32 x 8 classification tiles a 64 x 64 patch can touch
+constexpr int kSwTileRows = kSwPatchRows / 8 + 1, kSwTileCols = 3;      // 32 x 8 classification tiles a 64 x 64 patch can touch
 constexpr int kSwNDelta = 12;                        // pair offsets delta = -28, -24, ..., 16
 
 // smallest radius at which quad offset delta = (first output column of the block) - (first source of the quad) pairs them:
@@ -56,7 +58,7 @@ constexpr int kSwNDelta = 12;                        // pair offsets delta = -28
 __host__ __device__ constexpr int swNeed(int delta) { return delta > 3 ? delta - 3 : (delta < -15 ? -delta - 15 : 0); }
 
 // dynamic LDS (floats): the output tile [96][kSwPitch], then the weight tables [wave][64][kSwTS]
-constexpr int kSwLdsTab = kSwOut * kSwPitch;
+constexpr int kSwLdsTab = kSwOutRows * kSwPitch;
 constexpr int kSwLdsWords = kSwLdsTab + kSwWaves * 64 * kSwTS;
 
 // erf(t), t >= 0, for the tables of sources sharper than sigma = 1.4 pixels: the two branches of rtd_erf_det (include/rtd_detmath.h:
@@ -91,35 +93,43 @@ __device__ inline float swErf(float t) {
 // One (source row, layer): tables of the wave's 64 sources -> LDS. Entry i of a source = w * e_i for i <= its own batch radius, zero
 // up to the largest index the previous row-layer of this wave wrote (the lookups never clamp per source, only to the guard).
 // e_i: pixel-integrated Gaussian, the Taylor series of k_superpose_mfma for 1/sigma <= 0.5 (< 3e-8 absolute), erf differences above.
+template <bool ALL>
+__device__ inline void swBuildSeries(float* __restrict__ m, float rs, float w, int rhoS, int rhoRow, bool dead, bool series) {
+    const float r = dead ? 0.25f : rs;                               // (a dead ray's 1/sigma is +inf: keep the arithmetic finite, the values are not stored)
+    const float h2 = r * r, h4 = h2 * h2;
+    const float k1 = h2 * (1.0f / 24.0f), k2 = h4 * (1.0f / 1920.0f), k3 = h4 * h2 * (1.0f / 322560.0f);
+    const float c0 = 1.0f - 2.0f * k1 + 12.0f * k2 - 120.0f * k3;
+    const float c1 = (4.0f * k1 - 48.0f * k2 + 720.0f * k3) * h2;
+    const float c2 = (16.0f * k2 - 480.0f * k3) * h4;
+    const float c3 = 64.0f * k3 * (h4 * h2);
+    float q = __builtin_amdgcn_exp2f(-1.4426950409f * h2), gq = 0.5641895835f * r * w;   // gq = w * rs/sqrt(pi) * exp(-x_i^2)
+    const float cq = q * q;
+    if (ALL || series) m[0] = dead ? 0.0f : c0 * gq;
+    gq *= q; q *= cq;
+    for (int i = 1; i <= rhoRow; i += 2) {
+        const float w0 = (float)(i * i), w1 = (float)((i + 1) * (i + 1));
+        const float s0 = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(c3, w0, c2), w0, c1), w0, c0);
+        const float s1 = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(c3, w1, c2), w1, c1), w1, c0);
+        const float g1 = gq * q, q1 = q * cq;
+        const float ea = gq * s0, eb = g1 * s1;
+        gq = g1 * q1; q = q1 * cq;
+        if (ALL || series) {
+            m[i] = i <= rhoS ? ea : 0.0f;
+            if (i + 1 <= rhoRow) m[i + 1] = i + 1 <= rhoS ? eb : 0.0f;
+        }
+    }
+}
+
+// One (source row, layer): tables of the wave's 64 sources -> LDS. Entry i of a source = w * e_i for i <= its own batch radius, zero
+// up to the largest index the previous row-layer of this wave wrote (the lookups never clamp per source, only to the guard).
+// e_i: pixel-integrated Gaussian, the Taylor series of k_superpose_mfma for 1/sigma <= 0.5 (< 3e-8 absolute), erf differences above.
 __device__ inline void swBuild(float* __restrict__ m, float rs, float w, int rhoS, int rhoRow, int prevRho) {
     const bool dead = rhoS < 0;
     const bool series = dead || rs <= 0.5f;
-    if (__any(series)) {
-        const float r = dead ? 0.25f : rs;                           // (a dead ray's 1/sigma is +inf: keep the arithmetic finite, the values are not stored)
-        const float h2 = r * r, h4 = h2 * h2;
-        const float k1 = h2 * (1.0f / 24.0f), k2 = h4 * (1.0f / 1920.0f), k3 = h4 * h2 * (1.0f / 322560.0f);
-        const float c0 = 1.0f - 2.0f * k1 + 12.0f * k2 - 120.0f * k3;
-        const float c1 = (4.0f * k1 - 48.0f * k2 + 720.0f * k3) * h2;
-        const float c2 = (16.0f * k2 - 480.0f * k3) * h4;
-        const float c3 = 64.0f * k3 * (h4 * h2);
-        float q = __builtin_amdgcn_exp2f(-1.4426950409f * h2), gq = 0.5641895835f * r * w;   // gq = w * rs/sqrt(pi) * exp(-x_i^2)
-        const float cq = q * q;
-        if (series) m[0] = dead ? 0.0f : c0 * gq;
-        gq *= q; q *= cq;
-        for (int i = 1; i <= rhoRow; i += 2) {
-            const float w0 = (float)(i * i), w1 = (float)((i + 1) * (i + 1));
-            const float s0 = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(c3, w0, c2), w0, c1), w0, c0);
-            const float s1 = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(c3, w1, c2), w1, c1), w1, c0);
-            const float g1 = gq * q, q1 = q * cq;
-            const float ea = gq * s0, eb = g1 * s1;
-            gq = g1 * q1; q = q1 * cq;
-            if (series) {
-                m[i] = i <= rhoS ? ea : 0.0f;
-                if (i + 1 <= rhoRow) m[i + 1] = i + 1 <= rhoS ? eb : 0.0f;
-            }
-        }
-    }
-    if (__any(!series)) {                                            // sources sharper than sigma = 1.4 pixels (few entries)
+    if (__all(series)) swBuildSeries<true>(m, rs, w, rhoS, rhoRow, dead, true);      // (the usual case: no per-store predicate)
+    else {
+        if (__any(series)) swBuildSeries<false>(m, rs, w, rhoS, rhoRow, dead, series);
+        // sources sharper than sigma = 1.4 pixels (few entries)
         const float r = series ? 1.0f : rs;                          // (finite arguments on the lanes whose values are not stored)
         float erfNew = swErf(r * 0.5f), erfOld = -erfNew;
         for (int i = 0; i <= rhoRow; ++i) {
@@ -141,25 +151,43 @@ struct SwLevel {
     static constexpr int count() { int n = 0; for (int q = 0; q < 16; ++q) for (int t = 0; t < kSwNCB; ++t) n += swNeed(16 * (t - 1) - 4 * q) == NEED ? 1 : 0; return n; }
     static constexpr int kN = count();
 };
-template <int NEED>
-__device__ inline void swLevelLoad(float (&b)[SwLevel<NEED>::kN], const float* __restrict__ lds, const int (&idxB)[kSwNDelta]) {
+// quads [Q0, Q1) of a level (a patch whose last columns lie outside the field's dose rectangle skips its last quads: their tables are zero)
+template <int NEED, int Q0, int Q1>
+__device__ inline void swLevelLoadQ(float (&b)[SwLevel<NEED>::kN], const float* __restrict__ lds, const int (&idxB)[kSwNDelta]) {
     int n = 0;
 #pragma unroll
     for (int q = 0; q < 16; ++q)
 #pragma unroll
         for (int t = 0; t < kSwNCB; ++t) {
             const int delta = 16 * (t - 1) - 4 * q;                  // a constant once unrolled
-            if (swNeed(delta) == NEED) b[n++] = lds[idxB[(delta + 28) >> 2] + q * 4 * kSwTS];
+            if (swNeed(delta) == NEED) {
+                if (q >= Q0 && q < Q1) b[n] = lds[idxB[(delta + 28) >> 2] + q * 4 * kSwTS];
+                ++n;
+            }
         }
 }
-template <int NEED>
-__device__ inline void swLevelMul(f32x4 (&acc)[kSwNCB], const float (&a)[16], const float (&b)[SwLevel<NEED>::kN]) {
+template <int NEED, int Q0, int Q1>
+__device__ inline void swLevelMulQ(f32x4 (&acc)[kSwNCB], const float (&a)[16], const float (&b)[SwLevel<NEED>::kN]) {
     int n = 0;
 #pragma unroll
     for (int q = 0; q < 16; ++q)
 #pragma unroll
         for (int t = 0; t < kSwNCB; ++t)
-            if (swNeed(16 * (t - 1) - 4 * q) == NEED) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b[n++], acc[t], 0, 0, 0);
+            if (swNeed(16 * (t - 1) - 4 * q) == NEED) {
+                if (q >= Q0 && q < Q1) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b[n], acc[t], 0, 0, 0);
+                ++n;
+            }
+}
+constexpr int kSwQCut = 14;                                          // quads [0, 14) always, [14, 16) only when the patch has more than 56 columns
+template <int NEED>
+__device__ inline void swLevelLoad(float (&b)[SwLevel<NEED>::kN], const float* __restrict__ lds, const int (&idxB)[kSwNDelta], bool tail) {
+    swLevelLoadQ<NEED, 0, kSwQCut>(b, lds, idxB);
+    if (tail) swLevelLoadQ<NEED, kSwQCut, 16>(b, lds, idxB);
+}
+template <int NEED>
+__device__ inline void swLevelMul(f32x4 (&acc)[kSwNCB], const float (&a)[16], const float (&b)[SwLevel<NEED>::kN], bool tail) {
+    swLevelMulQ<NEED, 0, kSwQCut>(acc, a, b);
+    if (tail) swLevelMulQ<NEED, kSwQCut, 16>(acc, a, b);
 }
 
 __global__ __launch_bounds__(64 * kSwWaves, 4) void k_superpose_sweep(const float* __restrict__ bevIdd, const float* __restrict__ bevRSigmaEff,
@@ -192,12 +220,12 @@ __global__ __launch_bounds__(64 * kSwWaves, 4) void k_superpose_sweep(const floa
     // the rectangle of rays that carry dose anywhere in the field, cut into 64 x 64 patches from its own corner
     int ux0 = st->actUnion[0], uy0 = st->actUnion[1], ux1 = -st->actUnion[2], uy1 = -st->actUnion[3];
     if (ux0 > ux1 || uy0 > uy1 || ux0 < 0 || uy0 < 0) { ux0 = 0; uy0 = 0; ux1 = 0; uy1 = 0; }   // no dose at all: one patch of zeros writes the slices
-    const int nPX = (ux1 - ux0) / kSwPatch + 1, nPY = (uy1 - uy0) / kSwPatch + 1;
+    const int nPX = (ux1 - ux0) / kSwPatch + 1, nPY = (uy1 - uy0) / kSwPatchRows + 1;
     const int ppx = p % nPXg, ppy = p / nPXg;
     if (ppx >= nPX || ppy >= nPY) return;
     if (k >= st->swGroupPassive[g]) return;                          // no layer of this group deposits at k
-    const int sx0 = ux0 + kSwPatch * ppx, sy0 = uy0 + kSwPatch * ppy;
-    const int nRows = min(kSwPatch, uy1 - sy0 + 1), nCols = min(kSwPatch, ux1 - sx0 + 1);
+    const int sx0 = ux0 + kSwPatch * ppx, sy0 = uy0 + kSwPatchRows * ppy;
+    const int nRows = min(kSwPatchRows, uy1 - sy0 + 1), nCols = min(kSwPatch, ux1 - sx0 + 1);
     const int W = fc.W, H = fc.H, S = fc.S;
     const int nTiles = fc.tilesX * fc.tilesY;
     const int tx0 = sx0 >> 5, ty0 = sy0 >> 3;
@@ -219,7 +247,7 @@ __global__ __launch_bounds__(64 * kSwWaves, 4) void k_superpose_sweep(const floa
         }
         if (lane == 0) { sMisc[0] = __popcll(mask); sMisc[1] = 0; }
     }
-    for (int i = tid; i < kSwOut * kSwPitch; i += 64 * kSwWaves) sOut[i] = 0.0f;
+    for (int i = tid; i < kSwOutRows * kSwPitch; i += 64 * kSwWaves) sOut[i] = 0.0f;
     float* tab = sw + kSwLdsTab + wv * 64 * kSwTS;
     for (int i = lane; i < 64 * kSwTS; i += 64) tab[i] = 0.0f;       // guards (and everything the lookups may reach before it is written)
     __syncthreads();
@@ -251,6 +279,7 @@ __global__ __launch_bounds__(64 * kSwWaves, 4) void k_superpose_sweep(const floa
     }
     const int sx = sx0 + lane;
     const bool colOk = lane < nCols;
+    const bool qTail = nCols > 4 * kSwQCut;                          // (block-uniform)
     const int effCol = (sx >> 5) - tx0;
 
     // ---- the wave's row-layers in (row, layer) order; dose and 1/sigma of the next one are requested before this one is multiplied ----
@@ -301,27 +330,31 @@ __global__ __launch_bounds__(64 * kSwWaves, 4) void k_superpose_sweep(const floa
             {
                 float a[16], b0[SwLevel<0>::kN], b1[SwLevel<1>::kN];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) a[q] = sw[idxA + q * 4 * kSwTS];
-                swLevelLoad<0>(b0, sw, idxB);
-                if (rhoRow >= 1) swLevelLoad<1>(b1, sw, idxB);
+                for (int q = 0; q < kSwQCut; ++q) a[q] = sw[idxA + q * 4 * kSwTS];
+                if (qTail) {
+#pragma unroll
+                    for (int q = kSwQCut; q < 16; ++q) a[q] = sw[idxA + q * 4 * kSwTS];
+                }
+                swLevelLoad<0>(b0, sw, idxB, qTail);
+                if (rhoRow >= 1) swLevelLoad<1>(b1, sw, idxB, qTail);
                 __builtin_amdgcn_sched_barrier(0);
-                swLevelMul<0>(acc, a, b0);
+                swLevelMul<0>(acc, a, b0, qTail);
                 if (rhoRow >= 1) {
                     float b5[SwLevel<5>::kN];
-                    if (rhoRow >= 5) swLevelLoad<5>(b5, sw, idxB);
+                    if (rhoRow >= 5) swLevelLoad<5>(b5, sw, idxB, qTail);
                     __builtin_amdgcn_sched_barrier(0);
-                    swLevelMul<1>(acc, a, b1);
+                    swLevelMul<1>(acc, a, b1, qTail);
                     if (rhoRow >= 5) {
                         float b9[SwLevel<9>::kN];
-                        if (rhoRow >= 9) swLevelLoad<9>(b9, sw, idxB);
+                        if (rhoRow >= 9) swLevelLoad<9>(b9, sw, idxB, qTail);
                         __builtin_amdgcn_sched_barrier(0);
-                        swLevelMul<5>(acc, a, b5);
+                        swLevelMul<5>(acc, a, b5, qTail);
                         if (rhoRow >= 9) {
                             float b13[SwLevel<13>::kN];
-                            if (rhoRow >= 13) swLevelLoad<13>(b13, sw, idxB);
+                            if (rhoRow >= 13) swLevelLoad<13>(b13, sw, idxB, qTail);
                             __builtin_amdgcn_sched_barrier(0);
-                            swLevelMul<9>(acc, a, b9);
-                            if (rhoRow >= 13) swLevelMul<13>(acc, a, b13);
+                            swLevelMul<9>(acc, a, b9, qTail);
+                            if (rhoRow >= 13) swLevelMul<13>(acc, a, b13, qTail);
                         }
                     }
                 }
@@ -426,9 +459,9 @@ __global__ __launch_bounds__(64 * kSwWaves, 4) void k_superpose_sweep(const floa
                     for (int u = 0; u < kU; ++u) {
                         const int pix = pix0 + u * 64 * kSwWaves;
                         const int py = pix / bevW, px = pix - py * bevW;
-                        const int orow = py - (uy0 + kSwPatch * qy + kMaxSuperpR - kSwMaxR);   // padded BEV row = ray row + 32; tile row 0 = ray row sy0 - 16
+                        const int orow = py - (uy0 + kSwPatchRows * qy + kMaxSuperpR - kSwMaxR);   // padded BEV row = ray row + 32; tile row 0 = ray row sy0 - 16
                         const int ocol = px - (ux0 + kSwPatch * qx + kMaxSuperpR - kSwMaxR);
-                        off[u] = (pix < nPix && (unsigned)orow < (unsigned)kSwOut && (unsigned)ocol < (unsigned)kSwOut) ? orow * kSwOut + ocol : -1;
+                        off[u] = (pix < nPix && (unsigned)orow < (unsigned)kSwOutRows && (unsigned)ocol < (unsigned)kSwOut) ? orow * kSwOut + ocol : -1;
                     }
                     for (int g0 = 0; g0 < G; g0 += 4) {
                         float v[4][kU];
