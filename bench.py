@@ -418,7 +418,11 @@ def main():
                 traffic, pmc = None, {}
         mfma_per_launch = pmc.get("mfma_insts_per_launch")
         valu_per_launch = pmc.get("valu_insts_per_launch")
-        roof = {"kernel": "rtd::k_superpose_mfma", "bound": "valu+mfma issue", "achieved": round(ks_gbs, 2), "peak": HBM_PEAK_GBS,
+        # the general superposition of the field: k_superpose_sweep when every batch radius is within its reach (<= 16), else k_superpose_mfma
+        ks_name = pmc.get("kernel") or ("rtd::k_superpose_sweep" if info["max_radius"] <= 16 and not os.environ.get("RTD_NO_SWEEP") else "rtd::k_superpose_mfma")
+        if os.environ.get("RTD_NO_SWEEP"):
+            ks_name, traffic, pmc = "rtd::k_superpose_mfma", None, {}      # (profiles/traffic.json describes the default path)
+        roof = {"kernel": ks_name, "bound": "valu+mfma issue", "achieved": round(ks_gbs, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(ks_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "avg_launch_ms": round(ks_ms, 4), "algorithmic_bytes_per_launch": alg["superposition"],
                 "note": "contract form: algorithmic bytes = SURVEY.md 8(d) superposition term 8*(R+P)*sum(A_l), against the 8 TB/s HBM peak. "

@@ -20,7 +20,10 @@ cp $OUT/stats/s_kernel_stats.csv $OUT/kernel_stats.csv
 cp $OUT/c2/s_kernel_stats.csv $OUT/c2_kernel_stats.csv
 grep "^{" $OUT/c2.log | tail -1 > $OUT/c2_run.json
 python3 profiles/pmc_summary.py $OUT/fetch/p_counter_collection.csv $OUT/write/p_counter_collection.csv > $OUT/pmc_fetch_write_kb.txt
-python3 profiles/pmc_summary.py k_superpose_mfma $OUT/sq1/p_counter_collection.csv $OUT/sq2/p_counter_collection.csv > $OUT/pmc_sq_superpose.txt
+python3 profiles/pmc_summary.py k_superpose_sweep $OUT/sq1/p_counter_collection.csv $OUT/sq2/p_counter_collection.csv > $OUT/pmc_sq_superpose.txt
+RTD_NO_SWEEP=1 rocprofv3 --kernel-trace --stats -d $OUT/nosweep -o s --output-format csv -- $BENCH > $OUT/nosweep.log 2>&1 || echo "no-sweep pass failed"
+cp $OUT/nosweep/s_kernel_stats.csv $OUT/nosweep_kernel_stats.csv
+grep "^{" $OUT/stats.log | tail -1 > $OUT/bench_under_rocprof.json
 python3 profiles/pmc_summary.py k_fill $OUT/sq1/p_counter_collection.csv $OUT/sq2/p_counter_collection.csv > $OUT/pmc_sq_fill.txt
 python3 profiles/pmc_summary.py --traffic-json $OUT/fetch/p_counter_collection.csv $OUT/write/p_counter_collection.csv $OUT/sq1/p_counter_collection.csv $OUT/sq2/p_counter_collection.csv > $OUT/traffic.json
 tail -1 $OUT/stats.log | cut -c1-400

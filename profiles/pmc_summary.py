@@ -32,15 +32,20 @@ def traffic(paths):
         if not m or "FETCH_SIZE" not in d or "WRITE_SIZE" not in d: continue
         f = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"]); w = sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
         out[m.group(1)] = {"fetch_size_kib": round(f, 3), "write_size_kib": round(w, 3), "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
-    if "k_superpose_mfma" in out:
-        out["k_superpose"] = dict(out["k_superpose_mfma"], kernel="rtd::k_superpose_mfma")
+    # the dominant kernel of the bench field: k_superpose_sweep when it took the field (every batch radius <= 16), else k_superpose_mfma
+    # (the other of the two returns at once or is not launched: its traffic is a few KiB)
+    cand = [k for k in ("k_superpose_sweep", "k_superpose_mfma") if k in out]
+    if cand:
+        dom = max(cand, key=lambda k: out[k]["hbm_bytes_per_launch"])
+        out["k_superpose"] = dict(out[dom], kernel="rtd::" + dom)
         # issue counters of the dominant kernel, when the SQ passes are given too (bench.py: roofline.issue_cycle_frac, mfma_tflops)
         for k, d in collect(paths).items():
-            if "k_superpose_mfma" not in k: continue
+            if dom not in k: continue
             mean = lambda c: sum(d[c]) / len(d[c]) if c in d else None
             if mean("SQ_INSTS_MFMA"): out["k_superpose"]["mfma_insts_per_launch"] = int(mean("SQ_INSTS_MFMA"))
             if mean("SQ_INSTS_VALU"): out["k_superpose"]["valu_insts_per_launch"] = int(mean("SQ_INSTS_VALU"))
             if mean("SQ_INSTS_SALU"): out["k_superpose"]["salu_insts_per_launch"] = int(mean("SQ_INSTS_SALU"))
+            if mean("SQ_INSTS_LDS"): out["k_superpose"]["lds_insts_per_launch"] = int(mean("SQ_INSTS_LDS"))
             # GRBM_GUI_ACTIVE sums the 8 XCDs: cycles of the launch = /8; SIMD-cycles = x 256 CUs x 4 SIMDs
             if mean("GRBM_GUI_ACTIVE"): out["k_superpose"]["simd_cycles_per_launch"] = int(mean("GRBM_GUI_ACTIVE") / 8 * 1024)
     print(json.dumps(out, indent=1))
