@@ -821,6 +821,11 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
                             f->dSigMin, f->dSigMax, (size_t)fc.L * fc.S};
     launchK(k_trace_scan, dim3((unsigned)(f->R / 64)), dim3(64, kScanWaves), scanLds, s, nullptr, ev(1), (const float*)f->dIdd, f->dWepl, fc.W, fc.H,
             (unsigned)fc.S, f->dFirstInside, f->dFirstOutside, f->dState, f->dBlockWeplMin, resetJob);
+    if (fc.spotNy <= kPlanConvMaxRows && std::getenv("RTD_SEPARATE_PLAN") == nullptr) {
+        // the plan and the spot -> ray convolution in one launch (k_plan_conv): neither reads what the other writes
+        launchK(k_plan_conv, dim3(fc.W / 32, (fc.H / 8 + 3) / 4, fc.L + 1), dim3(1024), (size_t)4 * fc.spotNy * 32 * sizeof(float), s, nullptr, ev(2),
+                (const float*)f->dSpotWeights, f->dRayWeights, f->dLayers, f->dState, (const float*)f->dBlockWeplMin, (int)(f->R / 64), f->dWeplMin, fc);
+    } else {
     k_plan<<<1, 1024, 0, s>>>(f->dState, f->dLayers, (const float*)f->dBlockWeplMin, (int)(f->R / 64), f->dWeplMin, fc);
     if (fc.spotNy <= kConvMaxRows) {
         // both passes in one launch, the x pass staged in LDS (k_conv)
@@ -830,6 +835,7 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
         k_conv_x<<<dim3(fc.W / 32, (fc.spotNy + 7) / 8, fc.L), blk, 0, s>>>(f->dSpotWeights, f->dConvInterm, f->dLayers, f->dState, fc);
         launchK(k_conv_y, dim3(fc.W / 32, fc.H / 8, fc.L), blk, 0, s, nullptr, ev(2), (const float*)f->dConvInterm, f->dRayWeights,
                 (const LayerPlan*)f->dLayers, (const FieldState*)f->dState, fc);
+    }
     }
     {
         const size_t fillLds = (size_t)(2 * h->lut.nSamples) * sizeof(float);   // the layer's two cumulative-IDD rows

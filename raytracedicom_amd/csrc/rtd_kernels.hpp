@@ -453,9 +453,28 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_trace_scan(const float* __r
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2: device-side plan = the host cut-off logic of kernel_wrapper.cu:784,792-802,829-849,923-924.
-__global__ __launch_bounds__(1024) void k_plan(FieldState* st, LayerPlan* layers, const float* __restrict__ blockWeplMin, int nScanBlocks,
-                                               int* __restrict__ weplMinBits, FieldConst fc) {
+// Entry plane of the beam (kernel_wrapper.cu:784, :838-849): depth of the first step inside the patient, the pixel spacing factors
+// there and a layer's spot sigma there. Evaluated by k_plan (which records them) AND by the spot -> ray convolution itself, with
+// these same expressions — so that the convolution needs nothing k_plan writes and the two can share a launch (k_plan_conv).
+struct EntryGeom { float entryZ, pxSpMultX, pxSpMultY; };
+__device__ inline EntryGeom entryGeom(int beamFirstInside, const FieldConst& fc) {
+    EntryGeom e;
+    e.entryZ = ((float)beamFirstInside) * fc.rayRes[2] + fc.rayOffset[2];
+    e.pxSpMultX = 1.0f - e.entryZ / fc.sourceDist[0];
+    e.pxSpMultY = 1.0f - e.entryZ / fc.sourceDist[1];
+    return e;
+}
+__device__ inline float entrySigma(const LayerPlan& p, float spotSigma, float entryZ, const FieldConst& fc) {
+    float s = sqrtf(p.airCoefA * entryZ * entryZ + p.airCoefB * entryZ + spotSigma * spotSigma);
+    if (fc.nuclearCorr == 3) s = 0.97f * s;                          // GAUSS_FIT, kernel_wrapper.cu:842-847
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: device-side plan = the host cut-off logic of kernel_wrapper.cu:784,792-802,829-849,923-924. One workgroup of nT threads
+// (tid = its linear thread index): its own launch (k_plan) or one block of k_plan_conv.
+__device__ inline void planBody(FieldState* st, LayerPlan* layers, const float* __restrict__ blockWeplMin, int nScanBlocks,
+                                int* __restrict__ weplMinBits, const FieldConst& fc, const int tid, const int nT) {
     __shared__ float weplMin[kMaxSteps];
     __shared__ float sPart[4][512];          // partial minima (steps <= 512: 2 or 4 threads per step)
     __shared__ int sGuaranteed;
@@ -466,7 +485,7 @@ __global__ __launch_bounds__(1024) void k_plan(FieldState* st, LayerPlan* layers
     {
         const int nParts = fc.S <= 256 ? 4 : (fc.S <= 512 ? 2 : 1);
         const float inf = __int_as_float(0x7f800000);
-        for (int idx = threadIdx.x; idx < fc.S * nParts; idx += blockDim.x) {
+        for (int idx = tid; idx < fc.S * nParts; idx += nT) {
             const int s0 = idx % fc.S, part = idx / fc.S;
             const int b0 = (int)((long long)nScanBlocks * part / nParts), b1 = (int)((long long)nScanBlocks * (part + 1) / nParts);
             float m = inf;
@@ -480,7 +499,7 @@ __global__ __launch_bounds__(1024) void k_plan(FieldState* st, LayerPlan* layers
             if (nParts == 1) weplMin[s0] = m; else sPart[part][s0] = m;
         }
         __syncthreads();
-        for (int s0 = threadIdx.x; s0 < fc.S; s0 += blockDim.x) {
+        for (int s0 = tid; s0 < fc.S; s0 += nT) {
             float m = nParts == 1 ? weplMin[s0] : sPart[0][s0];
             for (int part = 1; part < nParts; ++part) { const float t = sPart[part][s0]; m = t < m ? t : m; }
             weplMin[s0] = m;
@@ -488,25 +507,24 @@ __global__ __launch_bounds__(1024) void k_plan(FieldState* st, LayerPlan* layers
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         int first = st->beamFirstInside;
-        float entryZ = ((float)first) * fc.rayRes[2] + fc.rayOffset[2];
+        const EntryGeom eg = entryGeom(first, fc);
         int firstPastCutoffAll = findFirstLargerOrdered(weplMin, fc.S, fc.bpDepthCutoff * fc.maxPeakDepth);
         int guaranteed = firstPastCutoffAll < st->beamFirstOutside ? firstPastCutoffAll : st->beamFirstOutside;
         st->firstGuaranteedPassive = guaranteed;
-        st->entryZ = entryZ;
-        st->pxSpMultX = 1.0f - entryZ / fc.sourceDist[0];
-        st->pxSpMultY = 1.0f - entryZ / fc.sourceDist[1];
+        st->entryZ = eg.entryZ;
+        st->pxSpMultX = eg.pxSpMultX;
+        st->pxSpMultY = eg.pxSpMultY;
         st->empty = guaranteed > first ? 0 : 1;
-        sGuaranteed = guaranteed; sEntryZ = entryZ;
+        sGuaranteed = guaranteed; sEntryZ = eg.entryZ;
     }
     __syncthreads();
     const float entryZ = sEntryZ;
-    for (int l = threadIdx.x; l < fc.L; l += blockDim.x) {
+    for (int l = tid; l < fc.L; l += nT) {
         LayerPlan& p = layers[l];
-        p.entrySigmaX = sqrtf(p.airCoefA * entryZ * entryZ + p.airCoefB * entryZ + p.spotSigmaX * p.spotSigmaX);
-        p.entrySigmaY = sqrtf(p.airCoefA * entryZ * entryZ + p.airCoefB * entryZ + p.spotSigmaY * p.spotSigmaY);
-        if (fc.nuclearCorr == 3) { p.entrySigmaX = 0.97f * p.entrySigmaX; p.entrySigmaY = 0.97f * p.entrySigmaY; }   // GAUSS_FIT, kernel_wrapper.cu:842-847
+        p.entrySigmaX = entrySigma(p, p.spotSigmaX, entryZ, fc);
+        p.entrySigmaY = entrySigma(p, p.spotSigmaY, entryZ, fc);
         unsigned int localAfterLast = (unsigned int)findFirstLargerOrdered(weplMin, fc.S, fc.bpDepthCutoff * p.peakDepth);
         unsigned int g = (unsigned int)sGuaranteed;
         p.afterLast = (int)(localAfterLast < g ? localAfterLast : g);
@@ -514,12 +532,16 @@ __global__ __launch_bounds__(1024) void k_plan(FieldState* st, LayerPlan* layers
     __syncthreads();
     // k_fill's walks — (layer, role): role 0 the sigma walk, role 1 the dose walk — ranked by descending cost: steps of the layer x
     // a measured per-step weight of the role (155 : 100). Stable rank by counting; 2 L <= 512 entries.
-    for (int p = threadIdx.x; p < 2 * fc.L; p += blockDim.x) {
+    for (int p = tid; p < 2 * fc.L; p += nT) {
         const int a = layers[p >> 1].afterLast * ((p & 1) ? 100 : 155);
         int rank = 0;
         for (int u = 0; u < 2 * fc.L; ++u) { const int au = layers[u >> 1].afterLast * ((u & 1) ? 100 : 155); rank += (au > a || (au == a && u < p)) ? 1 : 0; }
         st->fillItems[rank] = (unsigned short)p;
     }
+}
+__global__ __launch_bounds__(1024) void k_plan(FieldState* st, LayerPlan* layers, const float* __restrict__ blockWeplMin, int nScanBlocks,
+                                               int* __restrict__ weplMinBits, FieldConst fc) {
+    planBody(st, layers, blockWeplMin, nScanBlocks, weplMinBits, fc, (int)threadIdx.x, (int)blockDim.x);
 }
 
 #define RTD_DM_FN __device__ inline
@@ -535,12 +557,13 @@ __global__ void k_conv_x(const float* __restrict__ in, float* __restrict__ out, 
     const int inWidth = fc.spotNx, height = fc.spotNy, outWidth = fc.W;
     const float inOutDelta = fc.spotDelta[0] / fc.rayRes[0];
     const float inOutOffset = (fc.spotOffset[0] - fc.rayOffset[0]) / fc.rayRes[0];
-    const float pixelSp = fc.rayRes[0] * st->pxSpMultX;
+    const EntryGeom eg = entryGeom(st->beamFirstInside, fc);
+    const float pixelSp = fc.rayRes[0] * eg.pxSpMultX;
     const float cut = fc.convSigmaCutoff;
     if (idxY < height) {
         const int outIdxX = blockDim.x * blockIdx.x + threadIdx.x;
         float res = 0.0f;
-        float sigmaEff = layers[z].entrySigmaX / pixelSp;
+        float sigmaEff = entrySigma(layers[z], layers[z].spotSigmaX, eg.entryZ, fc) / pixelSp;
         float rSigmaEff = (1.0f / sqrtf(2.0f)) / sigmaEff;
         int cur = f2iSat(ceilf(((float)outIdxX - (cut * sigmaEff + 0.5f) - inOutOffset) / inOutDelta));
         cur = cur < 0 ? 0 : cur;   // spots left of the map contribute nothing: skip them (bounded loop, same result)
@@ -562,12 +585,13 @@ __global__ void k_conv_y(const float* __restrict__ in, float* __restrict__ out, 
     const int width = fc.W, inHeight = fc.spotNy, outHeight = fc.H;
     const float inOutDelta = fc.spotDelta[1] / fc.rayRes[1];
     const float inOutOffset = (fc.spotOffset[1] - fc.rayOffset[1]) / fc.rayRes[1];
-    const float pixelSp = fc.rayRes[1] * st->pxSpMultY;
+    const EntryGeom eg = entryGeom(st->beamFirstInside, fc);
+    const float pixelSp = fc.rayRes[1] * eg.pxSpMultY;
     const float cut = fc.convSigmaCutoff;
     if (idxX < width) {
         const int outIdxY = blockDim.y * blockIdx.y + threadIdx.y;
         float res = 0.0f;
-        float sigmaEff = layers[z].entrySigmaY / pixelSp;
+        float sigmaEff = entrySigma(layers[z], layers[z].spotSigmaY, eg.entryZ, fc) / pixelSp;
         float rSigmaEff = (1.0f / sqrtf(2.0f)) / sigmaEff;
         int cur = f2iSat(ceilf(((float)outIdxY - (cut * sigmaEff + 0.5f) - inOutOffset) / inOutDelta));
         cur = cur < 0 ? 0 : cur;
@@ -589,17 +613,22 @@ __global__ void k_conv_y(const float* __restrict__ in, float* __restrict__ out, 
 // cheaper than a second launch with its round trip through memory: 10.7 us for the pair of kernels above, 5 us for this one.
 // Used whenever the spot map has at most kConvMaxRows rows (LDS tile of 32 floats per row).
 constexpr int kConvMaxRows = 384;
-__global__ __launch_bounds__(256) void k_conv(const float* __restrict__ in, float* __restrict__ out, const LayerPlan* __restrict__ layers,
-                                               const FieldState* __restrict__ st, FieldConst fc) {
-    extern __shared__ float sInterm[];                               // [row - rowLo][32]
-    const int z = blockIdx.z;
+// One 32 x 8 tile of rays of layer z: tile (bx, by), thread (tx, ty) of its 256 threads, sInterm = the tile's LDS rows. Contains ONE
+// __syncthreads(): every thread of the block calls it (a tile beyond the grid passes by >= gridY and only keeps the barrier).
+__device__ inline void convTile(const float* __restrict__ in, float* __restrict__ out, const LayerPlan* __restrict__ layers,
+                                const FieldState* __restrict__ st, const FieldConst& fc, const int bx, const int by, const int z,
+                                const int tx, const int ty, float* __restrict__ sInterm) {
     const int inWidth = fc.spotNx, inHeight = fc.spotNy, width = fc.W, outHeight = fc.H;
     const float cut = fc.convSigmaCutoff;
+    const bool tileIn = by * 8 < outHeight && z < fc.L;
+    const LayerPlan& lp = layers[tileIn ? z : 0];
+    // the entry plane from the tracer's result itself (same expressions as k_plan: the convolution does not wait for it)
+    const EntryGeom eg = entryGeom(st->beamFirstInside, fc);
     // y pass geometry (k_conv_y)
     const float inOutDeltaY = fc.spotDelta[1] / fc.rayRes[1];
     const float inOutOffsetY = (fc.spotOffset[1] - fc.rayOffset[1]) / fc.rayRes[1];
-    const float pixelSpY = fc.rayRes[1] * st->pxSpMultY;
-    const float sigmaEffY = layers[z].entrySigmaY / pixelSpY;
+    const float pixelSpY = fc.rayRes[1] * eg.pxSpMultY;
+    const float sigmaEffY = entrySigma(lp, lp.spotSigmaY, eg.entryZ, fc) / pixelSpY;
     const float rSigmaEffY = (1.0f / sqrtf(2.0f)) / sigmaEffY;
     auto firstRow = [&](int outIdxY) {
         int cur = f2iSat(ceilf(((float)outIdxY - (cut * sigmaEffY + 0.5f) - inOutOffsetY) / inOutDeltaY));
@@ -607,7 +636,7 @@ __global__ __launch_bounds__(256) void k_conv(const float* __restrict__ in, floa
     };
     // spot rows the tile's y pass can read: from the first row of its first output row to the end of the last one's loop (both are
     // monotone in the output row for a positive row spacing; otherwise all rows are staged)
-    const int oy0 = blockDim.y * blockIdx.y, oy1 = min(oy0 + (int)blockDim.y - 1, outHeight - 1);
+    const int oy0 = 8 * by, oy1 = min(oy0 + 8 - 1, outHeight - 1);
     int rowLo = 0, rowHi = inHeight;                                 // rowHi exclusive
     if (inOutDeltaY > 0.0f) {
         rowLo = firstRow(oy0);
@@ -617,18 +646,18 @@ __global__ __launch_bounds__(256) void k_conv(const float* __restrict__ in, floa
         rowHi = min(c, inHeight);
         rowLo = min(rowLo, rowHi);
     }
-    const int nRows = rowHi - rowLo;
+    const int nRows = tileIn ? rowHi - rowLo : 0;
     // ---- x pass (k_conv_x) for rows [rowLo, rowHi) x the tile's 32 columns ----
     {
         const float inOutDelta = fc.spotDelta[0] / fc.rayRes[0];
         const float inOutOffset = (fc.spotOffset[0] - fc.rayOffset[0]) / fc.rayRes[0];
-        const float pixelSp = fc.rayRes[0] * st->pxSpMultX;
-        const int tid = threadIdx.y * 32 + threadIdx.x;
+        const float pixelSp = fc.rayRes[0] * eg.pxSpMultX;
+        const int tid = ty * 32 + tx;
         for (int v = tid; v < nRows * 32; v += 256) {
             const int idxY = rowLo + (v >> 5);
-            const int outIdxX = blockDim.x * blockIdx.x + (v & 31);
+            const int outIdxX = 32 * bx + (v & 31);
             float res = 0.0f;
-            float sigmaEff = layers[z].entrySigmaX / pixelSp;
+            float sigmaEff = entrySigma(lp, lp.spotSigmaX, eg.entryZ, fc) / pixelSp;
             float rSigmaEff = (1.0f / sqrtf(2.0f)) / sigmaEff;
             int cur = f2iSat(ceilf(((float)outIdxX - (cut * sigmaEff + 0.5f) - inOutOffset) / inOutDelta));
             cur = cur < 0 ? 0 : cur;
@@ -645,21 +674,42 @@ __global__ __launch_bounds__(256) void k_conv(const float* __restrict__ in, floa
     }
     __syncthreads();
     // ---- y pass (k_conv_y) from the LDS tile ----
-    const int idxX = blockDim.x * blockIdx.x + threadIdx.x;
-    const int outIdxY = oy0 + threadIdx.y;
-    if (idxX < width && outIdxY < outHeight) {
+    const int idxX = 32 * bx + tx;
+    const int outIdxY = oy0 + ty;
+    if (tileIn && idxX < width && outIdxY < outHeight) {
         float res = 0.0f;
         int cur = firstRow(outIdxY);
         float dist = (float)cur * inOutDeltaY + inOutOffsetY - (float)outIdxY;
         while (dist < (cut * sigmaEffY + 0.5f) && cur < inHeight) {
             if (cur >= 0 && cur < inHeight)
                 res += 0.5f * (rtd_erf_det((dist + 0.5f) * rSigmaEffY) - rtd_erf_det((dist - 0.5f) * rSigmaEffY))
-                       * sInterm[(cur - rowLo) * 32 + threadIdx.x];
+                       * sInterm[(cur - rowLo) * 32 + tx];
             ++cur;
             dist = (float)cur * inOutDeltaY + inOutOffsetY - (float)outIdxY;
         }
         out[(size_t)z * width * outHeight + (size_t)outIdxY * width + idxX] = res;
     }
+}
+__global__ __launch_bounds__(256) void k_conv(const float* __restrict__ in, float* __restrict__ out, const LayerPlan* __restrict__ layers,
+                                               const FieldState* __restrict__ st, FieldConst fc) {
+    extern __shared__ float sInterm[];                               // [row - rowLo][32]
+    convTile(in, out, layers, st, fc, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)threadIdx.x, (int)threadIdx.y, sInterm);
+}
+
+// K2 and K3+K4 in ONE launch: neither needs the other (the convolution evaluates the entry plane itself), and each alone is a
+// latency-bound launch of a few microseconds on the field's critical path. Blocks of 1024 threads; z < L: four 32 x 8 ray tiles of
+// layer z (rows 4 by .. 4 by + 3 of the tile grid), each with its own LDS rows; block (0, 0, L): the plan.
+constexpr int kPlanConvMaxRows = 64;                                 // spot rows up to which the four tiles' LDS stays small (4 x 8 KiB)
+__global__ __launch_bounds__(1024) void k_plan_conv(const float* __restrict__ in, float* __restrict__ out, LayerPlan* layers, FieldState* st,
+                                                    const float* __restrict__ blockWeplMin, int nScanBlocks, int* __restrict__ weplMinBits, FieldConst fc) {
+    extern __shared__ float sInterm[];                               // [4 tiles][spotNy][32]
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.z == fc.L) {
+        if (blockIdx.x == 0 && blockIdx.y == 0) planBody(st, layers, blockWeplMin, nScanBlocks, weplMinBits, fc, tid, (int)blockDim.x);
+        return;
+    }
+    const int v = tid >> 8, t = tid & 255;
+    convTile(in, out, layers, st, fc, (int)blockIdx.x, 4 * (int)blockIdx.y + v, (int)blockIdx.z, t & 31, t >> 5, sInterm + (size_t)v * fc.spotNy * 32);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1037,6 +1087,7 @@ __global__ __launch_bounds__(256) void k_ks_plan(FieldState* stGlobal, LayerPlan
                                                  int doseNx, int doseNy, int doseNz, int G, int Gs, FieldState* __restrict__ hostMirror,
                                                  FieldState* __restrict__ stNuc, const unsigned int* __restrict__ sigMin,
                                                  const unsigned int* __restrict__ sigMax, int uniformEligible) {
+    const int tid = threadIdx.x, nT = blockDim.x;
     // The state record is completed in LDS and then written out — to device memory and to its pinned host mirror — by all threads,
     // one dword each per trip: this one-block launch sits on the field's critical path, and both a load of the record behind a
     // store to it and a serial copy over PCIe by one thread cost microseconds each.
@@ -1049,20 +1100,21 @@ __global__ __launch_bounds__(256) void k_ks_plan(FieldState* stGlobal, LayerPlan
     {
         const unsigned int* src = reinterpret_cast<const unsigned int*>(stGlobal);
         unsigned int* dst = reinterpret_cast<unsigned int*>(&sSt);
-        for (unsigned int i = threadIdx.x; i < sizeof(FieldState) / 4; i += blockDim.x) dst[i] = src[i];
+        for (unsigned int i = tid; i < sizeof(FieldState) / 4; i += nT) dst[i] = src[i];
     }
-    if (threadIdx.x == 0) { sMaxPassive = 0; sMaxRad = 0; sLive = 0ull; sSliceDiffers = 0; }
-    if (threadIdx.x < 32) sGroup[threadIdx.x] = 0;
-    if (threadIdx.x < 16) sGroupSw[threadIdx.x] = 0;
+    if (tid == 0) { sMaxPassive = 0; sMaxRad = 0; sLive = 0ull; sSliceDiffers = 0; }
+    if (tid < 32) sGroup[tid] = 0;
+    if (tid < 16) sGroupSw[tid] = 0;
     __syncthreads();
     FieldState* st = &sSt;
     const int first = st->beamFirstInside;
     const int au[4] = { st->actUnion[0], st->actUnion[1], st->actUnion[2], st->actUnion[3] };
-    for (int l = threadIdx.x; l < fc.L; l += blockDim.x) {
+    for (int l = tid; l < fc.L; l += nT) {
         LayerPlan& p = layers[l];
         int hist[kMaxSuperpR + 2], effRad[kMaxSuperpR + 2];          // one round trip for the histogram, one for the result
 #pragma unroll
         for (int i = 0; i < kMaxSuperpR + 2; ++i) hist[i] = p.hist[i];
+        const int lfp = p.layerFirstPassive;
         int layerMax = 0;
 #pragma unroll
         for (int i = 0; i < kMaxSuperpR + 2; ++i) { if (hist[i] > 0) layerMax = i; effRad[i] = i; }
@@ -1082,10 +1134,10 @@ __global__ __launch_bounds__(256) void k_ks_plan(FieldState* stGlobal, LayerPlan
 #pragma unroll
         for (int i = 0; i < kMaxSuperpR + 2; ++i) p.effRad[i] = effRad[i];
         atomicMax(&sMaxRad, layerMax);
-        atomicMax(&sMaxPassive, p.layerFirstPassive);
-        atomicMax(&sGroup[l % G], p.layerFirstPassive);
-        atomicMax(&sGroupSw[l % Gs], p.layerFirstPassive);
-        if (p.layerFirstPassive > first) atomicAdd(&sLive, (unsigned long long)(p.layerFirstPassive - first));
+        atomicMax(&sMaxPassive, lfp);
+        atomicMax(&sGroup[l % G], lfp);
+        atomicMax(&sGroupSw[l % Gs], lfp);
+        if (lfp > first) atomicAdd(&sLive, (unsigned long long)(lfp - first));
     }
     __syncthreads();
     // Uniform-sigma field (water)? No tile saw two sigma^2 (k_fill) and every depositing (layer, step) has one over all its tiles.
@@ -1096,10 +1148,10 @@ __global__ __launch_bounds__(256) void k_ks_plan(FieldState* stGlobal, LayerPlan
         //  test "+inf or equal" needs no step range, and with four pairs of loads in flight the 2 x L x S words cost ~5 us)
         int differs = 0;
         const int n = fc.L * fc.S;
-        for (int i0 = threadIdx.x; i0 < n; i0 += 4 * blockDim.x) {
+        for (int i0 = tid; i0 < n; i0 += 4 * nT) {
             unsigned int a[4], b[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int i = i0 + u * blockDim.x; a[u] = i < n ? sigMin[i] : 0x7f800000u; b[u] = i < n ? sigMax[i] : 0u; }
+            for (int u = 0; u < 4; ++u) { const int i = i0 + u * nT; a[u] = i < n ? sigMin[i] : 0x7f800000u; b[u] = i < n ? sigMax[i] : 0u; }
 #pragma unroll
             for (int u = 0; u < 4; ++u) if (a[u] != 0x7f800000u && a[u] != b[u]) differs = 1;   // (+inf: no live ray)
         }
@@ -1111,8 +1163,8 @@ __global__ __launch_bounds__(256) void k_ks_plan(FieldState* stGlobal, LayerPlan
         // long items. One tile per thread, stable rank by counting.
         __shared__ int sArea[kKsMaxOrder];
         const int nTX = (fc.bevW + kKsTileX - 1) / kKsTileX, nTY = (fc.bevH + kKsTileY - 1) / kKsTileY, n = nTX * nTY;
-        if (n <= kKsMaxOrder) {                                      // (kKsMaxOrder <= blockDim.x)
-            const int rr = min(sMaxRad, kMaxSuperpR), t = threadIdx.x;
+        if (n <= kKsMaxOrder) {                                      // (kKsMaxOrder <= nT)
+            const int rr = min(sMaxRad, kMaxSuperpR), t = tid;
             int area = 0;
             if (t < n) {
                 const int ox0 = (t % nTX) * kKsTileX, oy0 = (t / nTX) * kKsTileY;
@@ -1129,7 +1181,7 @@ __global__ __launch_bounds__(256) void k_ks_plan(FieldState* stGlobal, LayerPlan
             }
         }
     }
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         // (everything is computed in registers from values read once, and stored at the end: a load of *st behind a store to it is
         //  a full memory round trip, and this thread is the critical path of the launch)
         const int calcPassive = sMaxPassive;
@@ -1161,16 +1213,15 @@ __global__ __launch_bounds__(256) void k_ks_plan(FieldState* stGlobal, LayerPlan
         const unsigned int* src = reinterpret_cast<const unsigned int*>(&sSt);
         unsigned int* dst = reinterpret_cast<unsigned int*>(stGlobal);
         volatile unsigned int* mir = reinterpret_cast<volatile unsigned int*>(hostMirror);
-        for (unsigned int i = threadIdx.x; i < sizeof(FieldState) / 4; i += blockDim.x) {
+        for (unsigned int i = tid; i < sizeof(FieldState) / 4; i += nT) {
             const unsigned int v = src[i];
             dst[i] = v;
             if (hostMirror) mir[i] = v;
         }
         // NUCLEAR_CORR: a radius overflow of the primary field stops the halo's transfer as well
-        if (stNuc && threadIdx.x == 0 && sSt.errorFlags) stNuc->errorFlags = sSt.errorFlags;
+        if (stNuc && tid == 0 && sSt.errorFlags) stNuc->errorFlags = sSt.errorFlags;
     }
 }
-
 
 // ------------------------------------------------------------------------------------------------
 // NUCLEAR_CORR halo (default off): what the reference's nuclear launches do given its fill (see NucFill).

@@ -449,22 +449,34 @@ __global__ __launch_bounds__(64 * kSwWaves, 4) void k_superpose_sweep(const floa
         //      a round trip each). ----
         const int bevW = fc.bevW, bevH = fc.bevH, nPix = bevW * bevH;
         float* out = bevDose + (size_t)k * bevW * bevH;
-        constexpr int kU = 4;
-        for (int pix0 = tid; pix0 < nPix; pix0 += kU * 64 * kSwWaves) {
+        // the rectangle of the slice that the patches' tiles cover (padded BEV pixel = ray + 32; tile pixel 0 = ray sx0 - 16); zeros outside
+        const int bx0 = ux0 + kMaxSuperpR - kSwMaxR, by0 = uy0 + kMaxSuperpR - kSwMaxR;
+        const int bx1 = min(bx0 + kSwPatch * (nPX - 1) + kSwOut, bevW), by1 = min(by0 + kSwPatchRows * (nPY - 1) + kSwOutRows, bevH);   // exclusive
+        const int bw = bx1 - bx0, nIn = bw * (by1 - by0);
+        for (int pix = tid; pix < nPix; pix += 64 * kSwWaves) {
+            const int py = pix / bevW, px = pix - py * bevW;
+            if (px < bx0 || px >= bx1 || py < by0 || py >= by1) out[pix] = 0.0f;
+        }
+        constexpr int kU = 8;
+        for (int i0 = tid; i0 < nIn; i0 += kU * 64 * kSwWaves) {
             float sum[kU];
+            int pixOf[kU];
 #pragma unroll
-            for (int u = 0; u < kU; ++u) sum[u] = 0.0f;
+            for (int u = 0; u < kU; ++u) {
+                sum[u] = 0.0f;
+                const int i = i0 + u * 64 * kSwWaves;
+                const int ry = i / bw, rx = i - ry * bw;
+                pixOf[u] = i < nIn ? (by0 + ry) * bevW + bx0 + rx : -1;
+            }
             for (int qy = 0; qy < nPY; ++qy)
                 for (int qx = 0; qx < nPX; ++qx) {
                     const float* sl = slots + (((size_t)k * nPg + (qy * nPXg + qx)) * G) * kSwSlot;
                     int off[kU];
 #pragma unroll
                     for (int u = 0; u < kU; ++u) {
-                        const int pix = pix0 + u * 64 * kSwWaves;
-                        const int py = pix / bevW, px = pix - py * bevW;
-                        const int orow = py - (uy0 + kSwPatchRows * qy + kMaxSuperpR - kSwMaxR);   // padded BEV row = ray row + 32; tile row 0 = ray row sy0 - 16
-                        const int ocol = px - (ux0 + kSwPatch * qx + kMaxSuperpR - kSwMaxR);
-                        off[u] = (pix < nPix && (unsigned)orow < (unsigned)kSwOutRows && (unsigned)ocol < (unsigned)kSwOut) ? orow * kSwOut + ocol : -1;
+                        const int py = pixOf[u] / bevW, px = pixOf[u] - py * bevW;
+                        const int orow = py - (by0 + kSwPatchRows * qy), ocol = px - (bx0 + kSwPatch * qx);
+                        off[u] = (pixOf[u] >= 0 && (unsigned)orow < (unsigned)kSwOutRows && (unsigned)ocol < (unsigned)kSwOut) ? orow * kSwOut + ocol : -1;
                     }
                     for (int g0 = 0; g0 < G; g0 += 4) {
                         float v[4][kU];
@@ -482,10 +494,8 @@ __global__ __launch_bounds__(64 * kSwWaves, 4) void k_superpose_sweep(const floa
                     }
                 }
 #pragma unroll
-            for (int u = 0; u < kU; ++u) {
-                const int pix = pix0 + u * 64 * kSwWaves;
-                if (pix < nPix) out[pix] = sum[u];
-            }
+            for (int u = 0; u < kU; ++u)
+                if (pixOf[u] >= 0) out[pixOf[u]] = sum[u];
         }
     }
     if (dbg && lane == 0) {

@@ -227,6 +227,79 @@ def test_spot_map_taller_than_the_lds_tile(orc, engine, synth):
     assert info["ray_dims"][1] >= 240
 
 
+def test_c3_through_the_output_stationary_kernel(orc, engine, synth, ct512, monkeypatch):
+    """The bench field with k_superpose_sweep switched off (RTD_NO_SWEEP, read at field creation): k_superpose_mfma — the kernel that
+    takes the fields with batch radii above 16 — keeps its full-size parity evidence."""
+    monkeypatch.setenv("RTD_NO_SWEEP", "1")
+    scn = scenarios.hetero_ct(synth, n=512, angles=[0.0], ct=ct512)
+    _compare_field(orc, engine, scn, scn.beams[0])
+
+
+@pytest.mark.parametrize("spacing,want_big", [((0.5, 0.5), True), ((1.0, 1.0), False)])
+def test_general_superposition_kernel_is_chosen_on_the_device(orc, engine, synth, spacing, want_big):
+    """Rays 0.5 mm apart double the radii in pixels: the field's largest batch radius exceeds 16, k_superpose_sweep returns at once
+    and k_superpose_mfma writes the BEV dose (both are launched until a finished compute has told the host which one the field
+    needs). Same field object computed three times: first with both kernels in the stream, then with the one the hint names;
+    identical bits every time, and every intermediate against the oracle."""
+    ct, _ = scenarios.hetero_phantom(96)
+    scn = scenarios.hetero_ct(synth, n=96, spots=4, pitch=6.0, n_layers=3, angles=[0.0], steps=200, ct=ct)
+    beam = scenarios.make_field(synth, 96, 256.0 / 96, (-128.0, -128.0, -106.0), 0.0, 4, 6.0, 3, 21, steps=200, ray_spacing=spacing, weight_lo=400.0)
+    scn = scenarios.Scenario("rays %g mm" % spacing[0], synth, ct, scn.spacing, [beam])
+    dose, ref, timing, info = _compare_field(orc, engine, scn, beam)
+    assert (info["max_radius"] > 16) == want_big, info["max_radius"]
+    n = scn.n_voxels
+    with engine.Engine(0) as eng:
+        eng.set_luts(synth)
+        eng.set_ct(ct)
+        d = eng.device_alloc(4 * n)
+        fld = eng.create_field(beam, scn.dims)
+        for _ in range(3):
+            eng.device_zero(d, 4 * n)
+            fld.compute(d)
+            fld.finish()
+            out = np.empty_like(ct)
+            eng.to_host(out, d)
+            np.testing.assert_array_equal(out, dose)
+        fld.destroy()
+        eng.device_free(d)
+
+
+def test_the_two_general_superposition_kernels_agree(orc, engine, synth, monkeypatch):
+    """k_superpose_sweep (source rows swept, T[|dy|][x] on the matrix cores) and k_superpose_mfma (output tiles visited) on the same
+    heterogeneous field with 17 layers: BEV doses within 1e-5 of each other relative to the maximum region (same weights up to the
+    series threshold, different order of the sums), identical support, both within the parity bar of the oracle."""
+    ct, _ = scenarios.hetero_phantom(128)
+    scn = scenarios.hetero_ct(synth, n=128, spots=7, pitch=6.0, n_layers=17, angles=[20.0], source_dist=(1900.0, 2300.0), ct=ct)
+    ref = np.zeros_like(scn.ct)
+    of = orc.run_field(scn, scn.beams[0], ref, keep_layers=True)
+    W, H, L = of.info["ray_dims"]
+    obev = of.get("bev").reshape(-1, H + 64, W + 64)
+    res = {}
+    for name, env in (("sweep", None), ("mfma", "1")):
+        if env is None:
+            monkeypatch.delenv("RTD_NO_SWEEP", raising=False)
+        else:
+            monkeypatch.setenv("RTD_NO_SWEEP", env)
+        eng, fld, dose, timing, info, d_dose = _run_engine(engine, scn, scn.beams[0])
+        try:
+            res[name] = (fld.fetch("bev").reshape(-1, H + 64, W + 64).copy(), dose.copy())
+        finally:
+            fld.destroy(); eng.device_free(d_dose); eng.close()
+    monkeypatch.delenv("RTD_NO_SWEEP", raising=False)
+    (bs, ds), (bm, dm) = res["sweep"], res["mfma"]
+    big = obev > 1e-3 * obev.max()
+    assert (np.abs(bs.astype(np.float64) - bm)[big] / obev[big]).max() <= 1e-5
+    np.testing.assert_array_equal(bs[first_slice(of):] == 0, bm[first_slice(of):] == 0)
+    for b in (bs, bm):
+        _rel_close(b, obev, rtol=1e-4)
+    _rel_close(ds, ref, rtol=1e-4)
+    _rel_close(dm, ref, rtol=1e-4)
+
+
+def first_slice(of):
+    return int(of.info["beam_first_inside"])
+
+
 def test_wide_field_many_tiles(orc, engine, synth):
     """A field wider than the CT: 448 x 448 rays -> 128 superposition output tiles (> the 64 that get a work-ranked dispatch
     order) and 1568 fill blocks (> 4 per CU: the plain longest-first placement); every intermediate still matches."""
