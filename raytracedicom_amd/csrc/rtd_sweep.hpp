@@ -457,6 +457,44 @@ __global__ __launch_bounds__(64 * kSwWaves, 4) void k_superpose_sweep(const floa
             const int py = pix / bevW, px = pix - py * bevW;
             if (px < bx0 || px >= bx1 || py < by0 || py >= by1) out[pix] = 0.0f;
         }
+        if (nPX == 1 && nPY == 1) {
+            // One patch (the usual field): the tile rows of the groups as float4 — a quarter of the loads — through the L2 after an
+            // invalidate (the other blocks' tile stores went to the memory side: sc1).
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const float* sl = slots + ((size_t)k * nPg + (ppy * nPXg + ppx)) * G * kSwSlot;
+            constexpr int kQ = kSwOut / 4;                           // float4 per tile row
+            const int nRowsIn = by1 - by0;
+            for (int i0 = tid; i0 < nRowsIn * kQ; i0 += 2 * 64 * kSwWaves) {
+                float4 sum[2];
+                int idx[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) { sum[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); idx[u] = i0 + u * 64 * kSwWaves; if (idx[u] >= nRowsIn * kQ) idx[u] = -1; }
+                for (int g0 = 0; g0 < G; g0 += 4) {
+                    float4 v[4][2];
+#pragma unroll
+                    for (int gg = 0; gg < 4; ++gg)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const bool on = g0 + gg < G && k < st->swGroupPassive[min(g0 + gg, G - 1)] && idx[u] >= 0;
+                            v[gg][u] = on ? *reinterpret_cast<const float4*>(sl + (size_t)(g0 + gg) * kSwSlot + 4 * idx[u]) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        }
+#pragma unroll
+                    for (int gg = 0; gg < 4; ++gg)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) { sum[u].x += v[gg][u].x; sum[u].y += v[gg][u].y; sum[u].z += v[gg][u].z; sum[u].w += v[gg][u].w; }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (idx[u] >= 0) {
+                        const int ry = idx[u] / kQ, rx = 4 * (idx[u] - ry * kQ);
+                        float* o = out + (size_t)(by0 + ry) * bevW + bx0 + rx;
+                        if (bx0 + rx + 0 < bx1) o[0] = sum[u].x;
+                        if (bx0 + rx + 1 < bx1) o[1] = sum[u].y;
+                        if (bx0 + rx + 2 < bx1) o[2] = sum[u].z;
+                        if (bx0 + rx + 3 < bx1) o[3] = sum[u].w;
+                    }
+            }
+        } else {
         constexpr int kU = 8;
         for (int i0 = tid; i0 < nIn; i0 += kU * 64 * kSwWaves) {
             float sum[kU];
@@ -496,6 +534,7 @@ __global__ __launch_bounds__(64 * kSwWaves, 4) void k_superpose_sweep(const floa
 #pragma unroll
             for (int u = 0; u < kU; ++u)
                 if (pixOf[u] >= 0) out[pixOf[u]] = sum[u];
+        }
         }
     }
     if (dbg && lane == 0) {
