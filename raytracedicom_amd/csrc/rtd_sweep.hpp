@@ -208,7 +208,7 @@ __global__ __launch_bounds__(64 * kSwWaves, 4) void k_superpose_sweep(const floa
     __shared__ int sMisc[4];                                         // number of layer slots, flush ticket, "last block of the step"
     float* sOut = sw;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // ---- decode (block-uniform); the deepest steps (largest radii, most work) are dispatched first ----
+    // ---- decode (block-uniform); the deepest steps first (measured: ascending order 0.342 ms against 0.313 ms) ----
     // (group fastest, then step, patch slowest: the live blocks — steps [entry, passive) of the patches that hold dose — are then
     //  CONSECUTIVE block indices, which the dispatcher deals round-robin to the 8 XCDs. With the patch index in the middle the
     //  live blocks of the bench field, one patch of four, all had indices 16 j + 0..3 and landed on four of the eight XCDs.)
@@ -381,6 +381,7 @@ __global__ __launch_bounds__(64 * kSwWaves, 4) void k_superpose_sweep(const floa
         const long long dw0 = dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
         while (__hip_atomic_load(&sMisc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != ri) {}
         const long long dw1 = dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        __builtin_amdgcn_s_setprio(3);                               // the flush is the block's serial chain: its instructions go first
         if (rhoFlush >= 0) {
             // T[|dy| = 4 kq + r][column 16 t + li] -> rows (ri + 16) +- |dy| of the tile; the minus side skips dy = 0. Plain
             // read-modify-write: the ticket makes this wave the only writer.
@@ -416,6 +417,7 @@ __global__ __launch_bounds__(64 * kSwWaves, 4) void k_superpose_sweep(const floa
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // the tile writes precede the ticket
         if (lane == 0) __hip_atomic_store(&sMisc[1], ri + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_s_setprio(0);
         if (dbg) { dbgWait += dw1 - dw0; dbgFlush += (long long)__builtin_amdgcn_s_memtime() - dw1; }
     }
     const long long dbgWaveEnd = dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
@@ -545,7 +547,8 @@ __global__ __launch_bounds__(64 * kSwWaves, 4) void k_superpose_sweep(const floa
         long long* q = dbg + 8 * (size_t)blockIdx.x;
         q[0] = dbgT0; q[1] = dbgT1; q[2] = dbgT2; q[3] = dbgT3; q[4] = (long long)__builtin_amdgcn_s_memtime();
         q[5] = ((long long)k << 32) | (long long)(g << 8) | (lastBlock ? 1 : 0);
-        q[6] = nLay; q[7] = (long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+        q[6] = nLay;
+        q[7] = ((long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32) | (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // XCC_ID | HW_ID
     }
 }
 
