@@ -1,7 +1,7 @@
 #!/bin/bash
 # C5 (768^3 CT, voxel 1/3 mm; one field of the eight-angle plan per GPU) on ONE GPU: bench line, rocprofv3 kernel stats and the counters
 # SURVEY.md 8(d) names for C5 (HBM read / write bytes, LDS bank conflicts, VALU busy) for the field at 0 degrees.
-#   gpurun --timeout 900 -- 'bash profiles/collect_c5.sh'      -> gpurun_out/prof_c5/ (then copied to profiles/r02_c5_*)
+#   gpurun --timeout 900 -- 'bash profiles/collect_c5.sh'      -> gpurun_out/prof_c5/ (then copied to profiles/r03_c5_*)
 set -u
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/prof_c5
@@ -16,6 +16,6 @@ cd $R
 cp $OUT/stats/s_kernel_stats.csv $OUT/kernel_stats.csv
 grep "^{" $OUT/stats.log | tail -1 > $OUT/bench.json
 python3 profiles/pmc_summary.py $OUT/fetch/p_counter_collection.csv $OUT/write/p_counter_collection.csv > $OUT/pmc_fetch_write_kb.txt
-python3 profiles/pmc_summary.py k_superpose_mfma $OUT/sq/p_counter_collection.csv > $OUT/pmc_sq_superpose.txt
+python3 profiles/pmc_summary.py k_superpose_sweep $OUT/sq/p_counter_collection.csv > $OUT/pmc_sq_superpose.txt
 python3 profiles/pmc_summary.py k_fill $OUT/sq/p_counter_collection.csv > $OUT/pmc_sq_fill.txt
 tail -1 $OUT/bench.json | cut -c1-300
