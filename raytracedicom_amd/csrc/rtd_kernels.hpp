@@ -359,6 +359,8 @@ __global__ __launch_bounds__(64 * kTrRays) void k_trace_sample_t(const float* __
 // out of LDS, one serial chain each:
 //   wave 0: cumulSp (WEPL; written back into the chunk, then stored by all waves)
 //   wave 1: cumulHu -> beforeFirstInside (:173-176)        wave 2: hu > 150 -> lastInside (:177-180)
+// (Round 3, measured and dropped: 32 rays per block — 264 blocks instead of 132, the two chains in the halves of one wave. The
+//  kernel is bound by the length of the serial chains, not by per-CU bandwidth: 27 -> 60 us.)
 constexpr int kScanWaves = 16, kScanChunk = 256, kScanPerWave = kScanChunk / kScanWaves;
 __global__ __launch_bounds__(64 * kScanWaves) void k_trace_scan(const float* __restrict__ huBuf, float* __restrict__ bevCumulSp, int W, int H,
                                                                  unsigned int steps, int* __restrict__ firstInside, int* __restrict__ firstOutside,
@@ -476,34 +478,51 @@ __device__ inline float entrySigma(const LayerPlan& p, float spotSigma, float en
 __device__ inline void planBody(FieldState* st, LayerPlan* layers, const float* __restrict__ blockWeplMin, int nScanBlocks,
                                 int* __restrict__ weplMinBits, const FieldConst& fc, const int tid, const int nT) {
     __shared__ float weplMin[kMaxSteps];
-    __shared__ float sPart[4][512];          // partial minima (steps <= 512: 2 or 4 threads per step)
+    __shared__ float sPart[8][512];          // partial minima (steps <= 512: up to 8 threads per group of four steps)
     __shared__ int sGuaranteed;
     __shared__ float sEntryZ;
-    // sliceMinVar<float>, second level: smallest WEPL of every step over the scan's blocks. blockWeplMin is [block][step]: thread =
-    // step (coalesced), the blocks split over up to 4 threads per step, 16 loads in flight per thread (a dependent load here is a
-    // full round trip of a single workgroup: the launch is latency, not bandwidth).
+    // sliceMinVar<float>, second level: smallest WEPL of every step over the scan's blocks. blockWeplMin is [block][step]: a thread takes
+    // FOUR consecutive steps (one 16-byte load per block) of a share of the blocks, 8 loads in flight (a dependent load here is a
+    // full round trip of a single workgroup: this is latency, not bandwidth).
     {
-        const int nParts = fc.S <= 256 ? 4 : (fc.S <= 512 ? 2 : 1);
         const float inf = __int_as_float(0x7f800000);
-        for (int idx = tid; idx < fc.S * nParts; idx += nT) {
-            const int s0 = idx % fc.S, part = idx / fc.S;
-            const int b0 = (int)((long long)nScanBlocks * part / nParts), b1 = (int)((long long)nScanBlocks * (part + 1) / nParts);
-            float m = inf;
-            for (int b = b0; b < b1; b += 16) {
-                float t[16];
+        if ((fc.S & 3) == 0 && fc.S <= 512) {
+            const int nQuads = fc.S >> 2;
+            const int nParts = max(1, min(8, nT / nQuads));
+            for (int idx = tid; idx < nQuads * nParts; idx += nT) {
+                const int q = idx % nQuads, part = idx / nQuads;
+                const int b0 = (int)((long long)nScanBlocks * part / nParts), b1 = (int)((long long)nScanBlocks * (part + 1) / nParts);
+                float4 m = make_float4(inf, inf, inf, inf);
+                for (int b = b0; b < b1; b += 8) {
+                    float4 t[8];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) t[u] = b + u < b1 ? blockWeplMin[(size_t)(b + u) * fc.S + s0] : inf;
+                    for (int u = 0; u < 8; ++u)
+                        t[u] = b + u < b1 ? *reinterpret_cast<const float4*>(blockWeplMin + (size_t)(b + u) * fc.S + 4 * q) : make_float4(inf, inf, inf, inf);
 #pragma unroll
-                for (int u = 0; u < 16; ++u) m = t[u] < m ? t[u] : m;
+                    for (int u = 0; u < 8; ++u) { m.x = t[u].x < m.x ? t[u].x : m.x; m.y = t[u].y < m.y ? t[u].y : m.y; m.z = t[u].z < m.z ? t[u].z : m.z; m.w = t[u].w < m.w ? t[u].w : m.w; }
+                }
+                sPart[part][4 * q] = m.x; sPart[part][4 * q + 1] = m.y; sPart[part][4 * q + 2] = m.z; sPart[part][4 * q + 3] = m.w;
             }
-            if (nParts == 1) weplMin[s0] = m; else sPart[part][s0] = m;
-        }
-        __syncthreads();
-        for (int s0 = tid; s0 < fc.S; s0 += nT) {
-            float m = nParts == 1 ? weplMin[s0] : sPart[0][s0];
-            for (int part = 1; part < nParts; ++part) { const float t = sPart[part][s0]; m = t < m ? t : m; }
-            weplMin[s0] = m;
-            weplMinBits[s0] = __float_as_int(m);                      // kept for rtd_field_fetch("wepl_min")
+            __syncthreads();
+            for (int s0 = tid; s0 < fc.S; s0 += nT) {
+                float m = sPart[0][s0];
+                for (int part = 1; part < nParts; ++part) { const float t = sPart[part][s0]; m = t < m ? t : m; }
+                weplMin[s0] = m;
+                weplMinBits[s0] = __float_as_int(m);                  // kept for rtd_field_fetch("wepl_min")
+            }
+        } else {
+            for (int s0 = tid; s0 < fc.S; s0 += nT) {
+                float m = inf;
+                for (int b = 0; b < nScanBlocks; b += 16) {
+                    float t[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) t[u] = b + u < nScanBlocks ? blockWeplMin[(size_t)(b + u) * fc.S + s0] : inf;
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) m = t[u] < m ? t[u] : m;
+                }
+                weplMin[s0] = m;
+                weplMinBits[s0] = __float_as_int(m);
+            }
         }
     }
     __syncthreads();
