@@ -1,3 +1,4 @@
+# (not collected by pytest: an analysis script on the CPU oracle, kept beside the tests because only tests may use the oracle)
 import sys; import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from raytracedicom_amd import luts, scenarios

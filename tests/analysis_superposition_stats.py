@@ -1,3 +1,4 @@
+# (not collected by pytest: an analysis script on the CPU oracle, kept beside the tests because only tests may use the oracle)
 """Statistics of the superposition's work on a bench field (CPU oracle): per (layer, step) the dose-carrying rectangle, the number of
 dose-carrying rays, the batch radii; per step the max radius."""
 import sys, time
