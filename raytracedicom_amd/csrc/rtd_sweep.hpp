@@ -59,7 +59,8 @@ __host__ __device__ constexpr int swNeed(int delta) { return delta > 3 ? delta -
 
 // dynamic LDS (floats): the output tile [96][kSwPitch], then the weight tables [wave][64][kSwTS]
 constexpr int kSwLdsTab = kSwOutRows * kSwPitch;
-constexpr int kSwLdsWords = kSwLdsTab + kSwWaves * 64 * kSwTS;
+constexpr int kSwWaveLds = 64 * kSwTS;                    // a wave's tables
+constexpr int kSwLdsWords = kSwLdsTab + kSwWaves * kSwWaveLds;
 
 // erf(t), t >= 0, for the tables of sources sharper than sigma = 1.4 pixels: the two branches of rtd_erf_det (include/rtd_detmath.h:
 // t + t R(t^2) below 0.875, 1 - 2^P(t - 0.875) above) evaluated side by side and selected — no divergence, the hardware exp2 for
@@ -146,17 +147,27 @@ __device__ inline void swBuild(float* __restrict__ m, float rs, float w, int rho
 }
 
 // The pairs that come into reach at radius NEED (0, 1, 5, 9, 13): T += A(quad) * B(quad, column block). A row-layer of radius rho runs
-// the levels NEED <= rho one after the other. A level's B operands are requested from LDS in one burst (swLevelLoad) while the
-// previous level is on the matrix cores (swLevelMul): an MFMA never waits for a read issued just in front of it — with 2..4
-// waves per SIMD that round trip per MFMA was what the first version of this kernel spent its time on.
+// the levels NEED <= rho one after the other, each in runs of up to eight quads: a run's A and B operands are requested from LDS in
+// one burst, then its MFMAs follow (sched_barrier between them) — an MFMA never waits for a read issued just in front of it; with
+// 2..4 waves per SIMD that round trip per MFMA was what the first version of this kernel spent its time on. (Requesting the next
+// level's operands while the previous level multiplies measured the same, 0.311 ms, at 124 instead of 99 registers.)
 template <int NEED>
 struct SwLevel {
     static constexpr int count() { int n = 0; for (int q = 0; q < 16; ++q) for (int t = 0; t < kSwNCB; ++t) n += swNeed(16 * (t - 1) - 4 * q) == NEED ? 1 : 0; return n; }
     static constexpr int kN = count();
 };
+// Operand addresses of the pair offsets: the four of level 0 (delta = -12 .. 0) live in registers for the whole block; a higher level
+// has two offsets (delta = -15 - NEED and 3 + NEED: -16 / 4, -20 / 8, -24 / 12, -28 / 16), computed when the level runs (3 vector
+// instructions each).
+struct SwIdx {
+    int base, lk;                                                    // the lane's source of quad 0; li - kq
+    int d0[4];                                                       // delta = -12, -8, -4, 0
+    __device__ inline int at(int delta) const { return base + min(abs(delta + lk), kSwGuard); }
+};
 // quads [Q0, Q1) of a level (a patch whose last columns lie outside the field's dose rectangle skips its last quads: their tables are zero)
 template <int NEED, int Q0, int Q1>
-__device__ inline void swLevelLoadQ(float (&b)[SwLevel<NEED>::kN], const float* __restrict__ lds, const int (&idxB)[kSwNDelta]) {
+__device__ inline void swLevelLoadQ(float (&b)[SwLevel<NEED>::kN], const float* __restrict__ lds, const SwIdx& ix) {
+    const int lo = NEED == 0 ? 0 : ix.at(-15 - NEED), hi = NEED == 0 ? 0 : ix.at(3 + NEED);   // the level's two offsets
     int n = 0;
 #pragma unroll
     for (int q = 0; q < 16; ++q)
@@ -164,7 +175,8 @@ __device__ inline void swLevelLoadQ(float (&b)[SwLevel<NEED>::kN], const float* 
         for (int t = 0; t < kSwNCB; ++t) {
             const int delta = 16 * (t - 1) - 4 * q;                  // a constant once unrolled
             if (swNeed(delta) == NEED) {
-                if (q >= Q0 && q < Q1) b[n] = lds[idxB[(delta + 28) >> 2] + q * 4 * kSwTS];
+                const int idx = NEED == 0 ? ix.d0[(delta + 12) >> 2] : (delta < 0 ? lo : hi);
+                if (q >= Q0 && q < Q1) b[n] = lds[idx + q * 4 * kSwTS];
                 ++n;
             }
         }
@@ -181,18 +193,28 @@ __device__ inline void swLevelMulQ(f32x4 (&acc)[kSwNCB], const float (&a)[16], c
                 ++n;
             }
 }
+// One level for the quads [Q0, Q1): its A and B operands requested in one burst, then its MFMAs (registers: at most 2 x 8).
+template <int NEED, int Q0, int Q1>
+__device__ inline void swLevelRunQ(f32x4 (&acc)[kSwNCB], const float* __restrict__ lds, int idxA, const SwIdx& ix) {
+    float a[16], b[SwLevel<NEED>::kN];
+#pragma unroll
+    for (int q = Q0; q < Q1; ++q) {
+        bool any = false;
+#pragma unroll
+        for (int t = 0; t < kSwNCB; ++t) any = any || swNeed(16 * (t - 1) - 4 * q) == NEED;
+        if (any) a[q] = lds[idxA + q * 4 * kSwTS];
+    }
+    swLevelLoadQ<NEED, Q0, Q1>(b, lds, ix);
+    __builtin_amdgcn_sched_barrier(0);
+    swLevelMulQ<NEED, Q0, Q1>(acc, a, b);
+}
 constexpr int kSwQCut = 14;                                          // quads [0, 14) always, [14, 16) only when the patch has more than 56 columns
 template <int NEED>
-__device__ inline void swLevelLoad(float (&b)[SwLevel<NEED>::kN], const float* __restrict__ lds, const int (&idxB)[kSwNDelta], bool tail) {
-    swLevelLoadQ<NEED, 0, kSwQCut>(b, lds, idxB);
-    if (tail) swLevelLoadQ<NEED, kSwQCut, 16>(b, lds, idxB);
+__device__ inline void swLevelRun(f32x4 (&acc)[kSwNCB], const float* __restrict__ lds, int idxA, const SwIdx& ix, bool tail) {
+    swLevelRunQ<NEED, 0, 8>(acc, lds, idxA, ix);
+    swLevelRunQ<NEED, 8, kSwQCut>(acc, lds, idxA, ix);
+    if (tail) swLevelRunQ<NEED, kSwQCut, 16>(acc, lds, idxA, ix);
 }
-template <int NEED>
-__device__ inline void swLevelMul(f32x4 (&acc)[kSwNCB], const float (&a)[16], const float (&b)[SwLevel<NEED>::kN], bool tail) {
-    swLevelMulQ<NEED, 0, kSwQCut>(acc, a, b);
-    if (tail) swLevelMulQ<NEED, kSwQCut, 16>(acc, a, b);
-}
-
 __global__ __launch_bounds__(64 * kSwWaves, 4) void k_superpose_sweep(const float* __restrict__ bevIdd, const float* __restrict__ bevRSigmaEff,
                                                                    const unsigned char* __restrict__ tileRad, const LayerPlan* __restrict__ layers,
                                                                    const FieldState* __restrict__ st, FieldConst fc, int G, int nPXg, int nPYg,
@@ -251,8 +273,8 @@ __global__ __launch_bounds__(64 * kSwWaves, 4) void k_superpose_sweep(const floa
         if (lane == 0) { sMisc[0] = __popcll(mask); sMisc[1] = 0; }
     }
     for (int i = tid; i < kSwOutRows * kSwPitch; i += 64 * kSwWaves) sOut[i] = 0.0f;
-    float* tab = sw + kSwLdsTab + wv * 64 * kSwTS;
-    for (int i = lane; i < 64 * kSwTS; i += 64) tab[i] = 0.0f;       // guards (and everything the lookups may reach before it is written)
+    float* tab = sw + kSwLdsTab + wv * kSwWaveLds;
+    for (int i = lane; i < kSwWaveLds; i += 64) tab[i] = 0.0f;       // guards (and everything the lookups may reach before it is written)
     __syncthreads();
     const int nLay = sMisc[0];
     for (int i = tid; i < nLay * kSwTileRows * kSwTileCols; i += 64 * kSwWaves) {
@@ -272,14 +294,12 @@ __global__ __launch_bounds__(64 * kSwWaves, 4) void k_superpose_sweep(const floa
     if (dbg) dbgT1 = (long long)__builtin_amdgcn_s_memtime();
     // ---- per-lane operand addresses (float indices into the dynamic LDS), fixed for the whole block ----
     const int li = lane & 15, kq = lane >> 4;                        // MFMA 16x16x4: A[i = li][k = kq], B[k = kq][j = li], D[i = 4 kq + r][j = li]
-    const int tabBase = kSwLdsTab + wv * 64 * kSwTS + kq * kSwTS;    // the lane's source of quad 0
+    const int tabBase = kSwLdsTab + wv * kSwWaveLds + kq * kSwTS;    // the lane's source of quad 0
     const int idxA = tabBase + li;                                   // row |dy| = li of T
-    int idxB[kSwNDelta];
+    SwIdx idxB;                                                      // table entry min(|output column - source column|, guard) per pair offset
+    idxB.base = tabBase; idxB.lk = li - kq;
 #pragma unroll
-    for (int d = 0; d < kSwNDelta; ++d) {
-        const int dist = abs(-28 + 4 * d + li - kq);                 // |output column - source column| of the lane for pair offset delta
-        idxB[d] = tabBase + min(dist, kSwGuard);
-    }
+    for (int d = 0; d < 4; ++d) idxB.d0[d] = idxB.at(-12 + 4 * d);
     const int sx = sx0 + lane;
     const bool colOk = lane < nCols;
     const bool qTail = nCols > 4 * kSwQCut;                          // (block-uniform)
@@ -330,35 +350,14 @@ __global__ __launch_bounds__(64 * kSwWaves, 4) void k_superpose_sweep(const floa
             swBuild(tab + lane * kSwTS, rs, __builtin_amdgcn_sqrtf(dose), rhoS, rhoRow, prevRho);
             prevRho = rhoRow;
             rhoFlush = max(rhoFlush, rhoRow);
-            {
-                float a[16], b0[SwLevel<0>::kN], b1[SwLevel<1>::kN];
-#pragma unroll
-                for (int q = 0; q < kSwQCut; ++q) a[q] = sw[idxA + q * 4 * kSwTS];
-                if (qTail) {
-#pragma unroll
-                    for (int q = kSwQCut; q < 16; ++q) a[q] = sw[idxA + q * 4 * kSwTS];
-                }
-                swLevelLoad<0>(b0, sw, idxB, qTail);
-                if (rhoRow >= 1) swLevelLoad<1>(b1, sw, idxB, qTail);
-                __builtin_amdgcn_sched_barrier(0);
-                swLevelMul<0>(acc, a, b0, qTail);
-                if (rhoRow >= 1) {
-                    float b5[SwLevel<5>::kN];
-                    if (rhoRow >= 5) swLevelLoad<5>(b5, sw, idxB, qTail);
-                    __builtin_amdgcn_sched_barrier(0);
-                    swLevelMul<1>(acc, a, b1, qTail);
-                    if (rhoRow >= 5) {
-                        float b9[SwLevel<9>::kN];
-                        if (rhoRow >= 9) swLevelLoad<9>(b9, sw, idxB, qTail);
-                        __builtin_amdgcn_sched_barrier(0);
-                        swLevelMul<5>(acc, a, b5, qTail);
-                        if (rhoRow >= 9) {
-                            float b13[SwLevel<13>::kN];
-                            if (rhoRow >= 13) swLevelLoad<13>(b13, sw, idxB, qTail);
-                            __builtin_amdgcn_sched_barrier(0);
-                            swLevelMul<9>(acc, a, b9, qTail);
-                            if (rhoRow >= 13) swLevelMul<13>(acc, a, b13, qTail);
-                        }
+            swLevelRun<0>(acc, sw, idxA, idxB, qTail);
+            if (rhoRow >= 1) {
+                swLevelRun<1>(acc, sw, idxA, idxB, qTail);
+                if (rhoRow >= 5) {
+                    swLevelRun<5>(acc, sw, idxA, idxB, qTail);
+                    if (rhoRow >= 9) {
+                        swLevelRun<9>(acc, sw, idxA, idxB, qTail);
+                        if (rhoRow >= 13) swLevelRun<13>(acc, sw, idxA, idxB, qTail);
                     }
                 }
             }
