@@ -19,7 +19,7 @@ def main():
     torch.cuda.init()
     es = luts.synth_luts()
     ct, _ = scenarios.hetero_phantom(n)
-    angles = [0.0, 45.0, 90.0, 135.0, 180.0, 225.0, 270.0, 315.0]
+    angles = [float(a) for a in sys.argv[3:]] or [0.0, 45.0, 90.0, 135.0, 180.0, 225.0, 270.0, 315.0]
     scn = scenarios.hetero_ct(es, n=n, angles=angles, ct=ct)
     eng = engine.Engine(0)
     opt = abi.default_options()
@@ -41,7 +41,7 @@ def main():
                     if isinstance(v, float):
                         acc[k] = acc.get(k, 0.0) + v
         row = {k: round(v / steps, 4) for k, v in acc.items()}
-        row.update(ray_dims=info["ray_dims"], steps=int(beam.tracerSteps), live_steps=info["live_steps"],
+        row.update(ray_dims=info["ray_dims"], steps=int(beam.tracerSteps), live_steps=info["live_steps"], max_radius=info.get("max_radius"),
                    box_voxels=int(t.get("transfer_voxels", 0)))
         out["%g" % a] = row
         print(a, json.dumps(row), flush=True)

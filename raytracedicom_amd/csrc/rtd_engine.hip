@@ -24,6 +24,7 @@
 #include "rtd_geometry.hpp"
 #include "rtd_kernels.hpp"
 #include "rtd_sweep.hpp"
+#include "rtd_sweep_big.hpp"
 
 using namespace rtd;
 
@@ -51,6 +52,7 @@ struct rtd_handle_impl {
     size_t traceTLds = 0;         // dynamic-LDS cap set for k_trace_sample_t so far
     size_t uniLds = 0;            // ... for k_superpose_uniform
     bool sweepLdsSet = false;     // ... for k_superpose_sweep
+    bool sweepBigLdsSet = false;  // ... for k_superpose_sweep_big
     unsigned inputEpoch = 0;      // bumped whenever CT, LUTs or options change (fields re-test what they learned about their input)
     // LUTs
     bool haveLuts = false;
@@ -120,6 +122,7 @@ struct rtd_field_impl {
     int transferModeNuc = 0;
     long long* dFillDbg = nullptr; size_t fillDbgN = 0;   // RTD_FILL_DEBUG: per-block clock stamps of k_fill (diagnostics)
     long long* dSweepDbg = nullptr; size_t sweepDbgN = 0; // RTD_SWEEP_DEBUG: per-block clock stamps of k_superpose_sweep (diagnostics)
+    long long* dSweepBigDbg = nullptr; size_t sweepBigDbgN = 0; // ... and of k_superpose_sweep_big
     FieldState* dState = nullptr;
     FieldState* hState = nullptr;      // pinned host mirror of *dState (written by k_ks_plan), and its device-side address
     FieldState* dHostState = nullptr;
@@ -133,6 +136,9 @@ struct rtd_field_impl {
     // k_superpose_sweep (rtd_sweep.hpp): layer groups, patches of the ray grid, partial tiles [step][patch][group][96 x 96], arrival counters [step]
     int swGroups = 4, swPX = 1, swPY = 1;
     float* dSwSlots = nullptr; int* dSwCount = nullptr;
+    // k_superpose_sweep_big (rtd_sweep_big.hpp), the sources of batch radius 17 .. 32: its own layer groups, partial tiles [step][patch][group][128 x 128], counters
+    int bgGroups = kBgMaxGroups;
+    float* dSwSlotsBig = nullptr; int* dSwCountBig = nullptr;
     int radiusHint = -1;          // largest batch radius the last finished compute found (-1 unknown), under hintEpoch like uniformHint
     bool sweepEnabled = true;     // RTD_NO_SWEEP: every field through k_superpose_mfma
 };
@@ -479,9 +485,9 @@ int rtd_field_destroy(rtd_handle hh, rtd_field ff) {
     if (!h || !f) return RTD_ERR_INVALID_ARG;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = { f->dSpotWeights, f->dConvInterm, f->dRayWeights, f->dDensity, f->dWepl, f->dRrl, f->dIdd, f->dRSigma, f->dBev, f->dBevPart, f->dNodeCount, f->dSwSlots, f->dSwCount,
+    void* ptrs[] = { f->dSpotWeights, f->dConvInterm, f->dRayWeights, f->dDensity, f->dWepl, f->dRrl, f->dIdd, f->dRSigma, f->dBev, f->dBevPart, f->dNodeCount, f->dSwSlots, f->dSwCount, f->dSwSlotsBig, f->dSwCountBig,
                      f->dFirstInside, f->dFirstOutside, f->dFirstPassive, f->dWeplMin, f->dBlockWeplMin, f->dTileRad,
-                     f->dLayers, f->dState, f->dStepTab, f->dActive, f->dSigMin, f->dSigMax, f->dFillDbg, f->dSweepDbg,
+                     f->dLayers, f->dState, f->dStepTab, f->dActive, f->dSigMin, f->dSigMax, f->dFillDbg, f->dSweepDbg, f->dSweepBigDbg,
                      f->dNucSpotIdx, f->dNucRayWeights, f->dNucIdd, f->dNucRs, f->dNucBev, f->dNucEffT, f->dStateNuc };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (f->hState) (void)hipHostFree(f->hState);
@@ -632,13 +638,16 @@ static int createField(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dim
     while (f->swGroups > std::max(1, (L + kSwMaxLay - 1) / kSwMaxLay) &&
            (size_t)S * f->swPX * f->swPY * f->swGroups * kSwSlot * sizeof(float) > ((size_t)2 << 30)) --f->swGroups;
     f->sig.Gs = (size_t)f->swGroups;
+    f->bgGroups = std::max(1, std::min(kBgMaxGroups, L));
+    if ((size_t)S * f->swPX * f->swPY * f->bgGroups * kBgSlot * sizeof(float) > ((size_t)1 << 30)) f->bgGroups = 1;
+    if (f->sweepEnabled) f->sig.G = 0;      // (the partial BEV buffers of k_superpose_mfma exist only without the sweep)
     rtd_field_impl* husk = nullptr;
     for (size_t i = 0; i < h->fieldCache.size(); ++i)
         if (h->fieldCache[i]->sig == f->sig) { husk = h->fieldCache[i]; h->fieldCache.erase(h->fieldCache.begin() + (long)i); break; }
     if (husk) {
         f->dSpotWeights = husk->dSpotWeights; f->dConvInterm = husk->dConvInterm; f->dRayWeights = husk->dRayWeights;
         f->dDensity = husk->dDensity; f->dWepl = husk->dWepl; f->dRrl = husk->dRrl; f->dIdd = husk->dIdd; f->dRSigma = husk->dRSigma;
-        f->dBev = husk->dBev; f->dBevPart = husk->dBevPart; f->dNodeCount = husk->dNodeCount; f->dSwSlots = husk->dSwSlots; f->dSwCount = husk->dSwCount; f->dFirstInside = husk->dFirstInside; f->dFirstOutside = husk->dFirstOutside;
+        f->dBev = husk->dBev; f->dBevPart = husk->dBevPart; f->dNodeCount = husk->dNodeCount; f->dSwSlots = husk->dSwSlots; f->dSwCount = husk->dSwCount; f->dSwSlotsBig = husk->dSwSlotsBig; f->dSwCountBig = husk->dSwCountBig; f->dFirstInside = husk->dFirstInside; f->dFirstOutside = husk->dFirstOutside;
         f->dFirstPassive = husk->dFirstPassive; f->dWeplMin = husk->dWeplMin; f->dBlockWeplMin = husk->dBlockWeplMin; f->dTileRad = husk->dTileRad; f->dLayers = husk->dLayers;
         f->dState = husk->dState; f->dStepTab = husk->dStepTab; f->dActive = husk->dActive; f->dSigMin = husk->dSigMin; f->dSigMax = husk->dSigMax; f->hState = husk->hState; f->dHostState = husk->dHostState;
         for (int i = 0; i < 9; ++i) f->ev[i] = husk->ev[i];
@@ -650,9 +659,11 @@ static int createField(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dim
     A(&f->dSpotWeights, nSpot); A(&f->dConvInterm, (size_t)W * b->spot_ny * L); A(&f->dRayWeights, R * L);
     A(&f->dDensity, R * S); A(&f->dWepl, R * S); A(&f->dRrl, R * S); A(&f->dIdd, R * S * L); A(&f->dRSigma, R * S * L); A(&f->dBev, P * S);
     const size_t nOutTiles = (size_t)((fc.bevW + kKsTileX - 1) / kKsTileX) * ((fc.bevH + kKsTileY - 1) / kKsTileY);
-    A(&f->dBevPart, nOutTiles * kKsTileX * kKsTileY * S * f->ksGroups);
-    A(&f->dNodeCount, nOutTiles * S * 32);
-    A(&f->dSwSlots, (size_t)S * f->swPX * f->swPY * f->swGroups * kSwSlot); A(&f->dSwCount, (size_t)S);
+    if (!f->sweepEnabled) { A(&f->dBevPart, nOutTiles * kKsTileX * kKsTileY * S * f->ksGroups); A(&f->dNodeCount, nOutTiles * S * 32); }
+    else {
+        A(&f->dSwSlots, (size_t)S * f->swPX * f->swPY * f->swGroups * kSwSlot); A(&f->dSwCount, (size_t)S);
+        A(&f->dSwSlotsBig, (size_t)S * f->swPX * f->swPY * f->bgGroups * kBgSlot); A(&f->dSwCountBig, (size_t)S);
+    }
     A(&f->dFirstInside, R); A(&f->dFirstOutside, R); A(&f->dFirstPassive, R * L); A(&f->dWeplMin, (size_t)S); A(&f->dBlockWeplMin, (R / 64) * (size_t)S);
     A(&f->dTileRad, f->tileRadWords * 4); A(&f->dLayers, (size_t)L); A(&f->dState, (size_t)1); A(&f->dStepTab, (size_t)2 * S); A(&f->dActive, (size_t)4 * L * S); A(&f->dSigMin, (size_t)L * S); A(&f->dSigMax, (size_t)L * S);
     if (st != RTD_OK) { rtd_field_destroy(hh, reinterpret_cast<rtd_field>(f)); return st; }
@@ -708,8 +719,9 @@ static int createField(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dim
     // (the transfer reads the slices [entry, passive) only, and the superposition's reduce writes every pixel of those: slices
     //  outside hold stale values that nothing samples; a fresh buffer is cleared once so that a fetch of "bev" reads zeros there)
     if (fresh) e = hipMemset(f->dBev, 0, P * (size_t)S * sizeof(float));
-    if (fresh && e == hipSuccess) e = hipMemset(f->dNodeCount, 0, nOutTiles * (size_t)S * 32 * sizeof(int));
-    if (fresh && e == hipSuccess) e = hipMemset(f->dSwCount, 0, (size_t)S * sizeof(int));
+    if (fresh && e == hipSuccess && f->dNodeCount) e = hipMemset(f->dNodeCount, 0, nOutTiles * (size_t)S * 32 * sizeof(int));
+    if (fresh && e == hipSuccess && f->dSwCount) e = hipMemset(f->dSwCount, 0, (size_t)S * sizeof(int));
+    if (fresh && e == hipSuccess && f->dSwCountBig) e = hipMemset(f->dSwCountBig, 0, (size_t)S * sizeof(int));
     if (e != hipSuccess) { h->error = std::string("HIP error (clearing the BEV buffer / node counters): ") + hipGetErrorString(e); rtd_field_destroy(hh, reinterpret_cast<rtd_field>(f)); return RTD_ERR_HIP; }
     *out = reinterpret_cast<rtd_field>(f);
     return RTD_OK;
@@ -862,7 +874,7 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
     }
     launchK(k_ks_plan, dim3(1), dim3(256), 0, s, nullptr, f->ev[4], f->dState, f->dLayers, fc, f->rayIdxToDoseIdx, f->transfer0,
                           (int)f->doseDims[0], (int)f->doseDims[1], (int)f->doseDims[2], f->ksGroups, f->swGroups, f->dHostState, f->dStateNuc,
-                          (const unsigned int*)f->dSigMin, (const unsigned int*)f->dSigMax, tryUniform ? 1 : 0);
+                          (const unsigned int*)f->dSigMin, (const unsigned int*)f->dSigMax, tryUniform ? 1 : 0, f->sweepEnabled ? kSwMaxR : -1, f->bgGroups);
     if (fc.nuclearCorr) {
         const int nPix = (fc.nucW + 2 * kMaxSuperpR) * (fc.nucH + 2 * kMaxSuperpR);
         k_nuc_superpose<<<(nPix + 255) / 256, 256, 0, s>>>((const float*)f->dNucIdd, (const float*)f->dNucRs, (const int*)f->dNucEffT,
@@ -882,12 +894,15 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
                 (const FieldState*)f->dState, fc, (const unsigned int*)f->dSigMin, (const float*)f->dStepTab, f->dBev);
         ksStart = nullptr;
     }
-    // The general superposition is k_superpose_sweep when every batch radius of the field is within its reach (<= 16), else
-    // k_superpose_mfma. Which one is known on the device (FieldState::maxRadius, k_ks_plan): both are launched and one of them returns
-    // at once — until a finished compute has told the host, under the same CT / LUTs / options, which of the two it is.
+    // The general superposition is the row sweep in two launches: k_superpose_sweep for the sources whose batch radius is within its
+    // reach (<= 16; it writes every slice), then k_superpose_sweep_big for the rest (17 .. 32), added to the slices. Whether a field has
+    // such a rest is known on the device (FieldState::maxRadius, k_ks_plan): the second launch returns at once if not — and is left out
+    // once a finished compute has told the host, under the same CT / LUTs / options, that it does not. (RTD_NO_SWEEP: k_superpose_mfma,
+    // round 2's output-stationary kernel, takes everything — kept as a second implementation the tests compare the sweep with.)
     const bool radiusKnown = f->radiusHint >= 0 && f->hintEpoch == h->inputEpoch;
-    const bool runSweep = !knownUniform && f->sweepEnabled && !(radiusKnown && f->radiusHint > kSwMaxR);
-    const bool runMfma = !knownUniform && !(f->sweepEnabled && radiusKnown && f->radiusHint <= kSwMaxR);
+    const bool runSweep = !knownUniform && f->sweepEnabled;
+    const bool runBig = runSweep && !(radiusKnown && f->radiusHint <= kSwMaxR);
+    const bool runMfma = !knownUniform && !f->sweepEnabled;
     if (runSweep) {
         constexpr size_t swLds = (size_t)kSwLdsWords * sizeof(float);
         if (!h->sweepLdsSet) {
@@ -899,10 +914,25 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
             RTD_HIP(h, hipMalloc((void**)&f->dSweepDbg, f->sweepDbgN * sizeof(long long)));
             RTD_HIP(h, hipMemset(f->dSweepDbg, 0, f->sweepDbgN * sizeof(long long)));
         }
-        launchK(k_superpose_sweep, dim3((unsigned)(fc.S * f->swPX * f->swPY * f->swGroups)), dim3(64 * kSwWaves), swLds, s, ksStart, runMfma ? nullptr : f->ev[5],
+        launchK(k_superpose_sweep, dim3((unsigned)(fc.S * f->swPX * f->swPY * f->swGroups)), dim3(64 * kSwWaves), swLds, s, ksStart, runBig ? nullptr : f->ev[5],
                 (const float*)f->dIdd, (const float*)f->dRSigma, (const unsigned char*)f->dTileRad, (const LayerPlan*)f->dLayers, (const FieldState*)f->dState, fc,
                 f->swGroups, f->swPX, f->swPY, (const int*)f->dActive, f->dSwSlots, f->dSwCount, f->dBev, f->dSweepDbg);
         ksStart = nullptr;
+    }
+    if (runBig) {
+        constexpr size_t bgLds = (size_t)kBgLdsWords * sizeof(float);
+        if (!h->sweepBigLdsSet) {
+            RTD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_superpose_sweep_big), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bgLds));
+            h->sweepBigLdsSet = true;
+        }
+        if (!f->dSweepBigDbg && std::getenv("RTD_SWEEP_DEBUG")) {
+            f->sweepBigDbgN = (size_t)48 * fc.S * f->swPX * f->swPY * f->bgGroups;
+            RTD_HIP(h, hipMalloc((void**)&f->dSweepBigDbg, f->sweepBigDbgN * sizeof(long long)));
+            RTD_HIP(h, hipMemset(f->dSweepBigDbg, 0, f->sweepBigDbgN * sizeof(long long)));
+        }
+        launchK(k_superpose_sweep_big, dim3((unsigned)(fc.S * f->swPX * f->swPY * f->bgGroups)), dim3(64 * kSwWaves), bgLds, s, nullptr, f->ev[5],
+                (const float*)f->dIdd, (const float*)f->dRSigma, (const unsigned char*)f->dTileRad, (const LayerPlan*)f->dLayers, (const FieldState*)f->dState, fc,
+                f->bgGroups, f->swPX, f->swPY, (const int*)f->dActive, f->dSwSlotsBig, f->dSwCountBig, f->dBev, f->dSweepBigDbg);
     }
     if (runMfma) {
         const int nTX = (fc.bevW + kKsTileX - 1) / kKsTileX, nTY = (fc.bevH + kKsTileY - 1) / kKsTileY;
@@ -913,7 +943,7 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
         auto launchKs = [&](auto kernel) {
             launchK(kernel, dim3(nItems), dim3(64 * split), 0, s, ksStart, f->ev[5], (const float*)f->dIdd, (const float*)f->dRSigma,
                     f->dBevPart, (const unsigned char*)f->dTileRad, (const LayerPlan*)f->dLayers, (const FieldState*)f->dState, fc, nTX, nTY, G,
-                    (const int*)f->dActive, f->dBev, f->dNodeCount, f->sweepEnabled ? kSwMaxR : -1);
+                    (const int*)f->dActive, f->dBev, f->dNodeCount, -1);
         };
         if (split == 1) launchKs(k_superpose_mfma<1>); else if (split == 2) launchKs(k_superpose_mfma<2>); else launchKs(k_superpose_mfma<4>);
     }
@@ -1204,6 +1234,7 @@ int rtd_field_fetch(rtd_handle hh, rtd_field ff, const char* name, void* host_ou
     else if (nm == "bev") { src = f->dBev; n = 4 * (size_t)fc.bevW * fc.bevH * S; }
     else if (nm == "fill_debug" && f->dFillDbg) { src = f->dFillDbg; n = f->fillDbgN * sizeof(long long); }
     else if (nm == "sweep_debug" && f->dSweepDbg) { src = f->dSweepDbg; n = f->sweepDbgN * sizeof(long long); }
+    else if (nm == "sweep_big_debug" && f->dSweepBigDbg) { src = f->dSweepBigDbg; n = f->sweepBigDbgN * sizeof(long long); }
     else if (nm == "eff_radius" || nm == "layer_plan") {
         std::vector<LayerPlan> lp(L);
         RTD_HIP(h, hipMemcpy(lp.data(), f->dLayers, L * sizeof(LayerPlan), hipMemcpyDeviceToHost));

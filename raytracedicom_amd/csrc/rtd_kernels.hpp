@@ -42,6 +42,7 @@ struct LayerPlan {
     int layerFirstPassive;                             // kernel_wrapper.cu:952-957   (device, atomicMax)
     int hist[kMaxSuperpR + 2];                         // tilePrimRadCtrs             kernel_wrapper.cu:959-963
     int effRad[kMaxSuperpR + 2];                       // batch radius per tile radius kernel_wrapper.cu:966-976
+    int classLo[kMaxSuperpR + 2], classHi[kMaxSuperpR + 2];   // first / last step at which a tile of the layer has that radius class (k_fill)
 };
 
 struct FieldState {
@@ -59,6 +60,9 @@ struct FieldState {
     int empty;                      // nothing inside the patient for this beam
     int groupPassive[32];           // per superposition layer group: first step at which none of its layers deposits
     int swGroupPassive[16];         // the same for the layer groups of k_superpose_sweep (rtd_sweep.hpp: its own, smaller group count)
+    // ... and, per layer group of the sweep's SECOND launch (rtd_sweep_big.hpp), the steps [swBigFirst, swBigPassive) at which some
+    // layer of the group has a tile whose batch radius is beyond the reach of the first launch (16)
+    int swBigFirst[16], swBigPassive[16];
     int actUnion[4];                // minima of (x, y, -x, -y) over all rays that carry dose in any (layer, step)
     int bevLo[2], bevHi[2];         // padded-BEV rectangle outside which every slice is exactly zero (transfer early-out)
     // The slab the transfer samples: packW x packH pixels per slice, pixel (0, 0) = padded-BEV pixel (packX0, packY0), first
@@ -216,7 +220,7 @@ struct ResetJob {
 __device__ inline void resetFieldArrays(const ResetJob& j, size_t t, size_t nT) {
     for (size_t l = t; l < (size_t)j.L; l += nT) {
         j.layers[l].layerFirstPassive = 0; j.layers[l].afterLast = 0;
-        for (int i = 0; i < kMaxSuperpR + 2; ++i) { j.layers[l].hist[i] = 0; j.layers[l].effRad[i] = i; }
+        for (int i = 0; i < kMaxSuperpR + 2; ++i) { j.layers[l].hist[i] = 0; j.layers[l].effRad[i] = i; j.layers[l].classLo[i] = 0x7fffffff; j.layers[l].classHi[i] = -1; }
     }
     for (size_t i = t; i < j.nRadWords; i += nT) j.tileRadWords[i] = 0xFFFFFFFFu;    // every (layer, step, tile): "not classified"
     for (size_t i = t; i < j.nActive; i += nT) j.active[i] = 0x7f7f7f7f;             // empty dose rectangles (+large minima)
@@ -783,6 +787,7 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
     __shared__ float sSig[2][kFillBatch][256];                       // sigma walk: [buffer][step][ray] sigmaSq of the rays with a finite 1/sigma (-1: none)
     __shared__ unsigned long long sDoseMask[2][kFillBatch][4];       // dose walk: [buffer][step][wave] ballot of the rays that carry dose
     __shared__ int sHist[kMaxSuperpR + 2];
+    __shared__ int sClassLo[kMaxSuperpR + 2], sClassHi[kMaxSuperpR + 2];   // sigma walk: first / last step of this walk with a tile of that radius class
     __shared__ int sUni;                                             // sigma walk: every tile of this block so far had ONE sigma^2 over its live rays
 
     // Block placement. The walks differ in cost — the number of steps per layer (150..210 on C3), and a sigma walk is ~1.5 dose
@@ -831,7 +836,7 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
 
     if (role == 0) {
         // ================================ sigma walk ================================
-        if (tid < kMaxSuperpR + 2) sHist[tid] = 0;
+        if (tid < kMaxSuperpR + 2) { sHist[tid] = 0; sClassLo[tid] = 0x7fffffff; sClassHi[tid] = -1; }
         if (tid == 0) sUni = trackUniform;                           // 0: the field is known not to be uniform (or not eligible): nothing is tracked
         const float pInv = 0.5649718f, eCoef = 8.639415f;
         // E_s^2 and the empirical widening per NUCLEAR_CORR variant (kernel_wrapper.cu:228-245)
@@ -929,6 +934,8 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
                     rad = rad < 0 ? 0 : rad;
                     tileRad[((size_t)layer * fc.S + step0 + j) * nTiles + tileNo] = (unsigned char)rad;
                     atomicAdd(&sHist[rad], 1);
+                    atomicMin(&sClassLo[rad], (int)(step0 + j));
+                    atomicMax(&sClassHi[rad], (int)(step0 + j));
                 }
             }
         }
@@ -937,7 +944,11 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
         int mx = waveMaxI((int)afterLast);
         if ((tid & (kWave - 1)) == 0) atomicMax(&layers[layer].layerFirstPassive, mx);
         __syncthreads();
-        if (tid < kMaxSuperpR + 2 && sHist[tid] > 0) atomicAdd(&layers[layer].hist[tid], sHist[tid]);
+        if (tid < kMaxSuperpR + 2 && sHist[tid] > 0) {
+            atomicAdd(&layers[layer].hist[tid], sHist[tid]);
+            atomicMin(&layers[layer].classLo[tid], sClassLo[tid]);
+            atomicMax(&layers[layer].classHi[tid], sClassHi[tid]);
+        }
     } else {
         // ================================ dose walk ================================
         // cumulative IDD: rows floor(energyIdx), floor(energyIdx)+1 (CLAMP) and the row weight are layer constants
@@ -1105,7 +1116,7 @@ __device__ inline void transferBoxes(const FromFan& rayIdxToDoseIdx, int W, int 
 __global__ __launch_bounds__(256) void k_ks_plan(FieldState* stGlobal, LayerPlan* layers, FieldConst fc, FromFan rayIdxToDoseIdx, TransferParams tp0,
                                                  int doseNx, int doseNy, int doseNz, int G, int Gs, FieldState* __restrict__ hostMirror,
                                                  FieldState* __restrict__ stNuc, const unsigned int* __restrict__ sigMin,
-                                                 const unsigned int* __restrict__ sigMax, int uniformEligible) {
+                                                 const unsigned int* __restrict__ sigMax, int uniformEligible, int sweepMaxR, int Gb) {
     const int tid = threadIdx.x, nT = blockDim.x;
     // The state record is completed in LDS and then written out — to device memory and to its pinned host mirror — by all threads,
     // one dword each per trip: this one-block launch sits on the field's critical path, and both a load of the record behind a
@@ -1113,6 +1124,7 @@ __global__ __launch_bounds__(256) void k_ks_plan(FieldState* stGlobal, LayerPlan
     __shared__ FieldState sSt;
     __shared__ int sMaxPassive;
     __shared__ int sGroup[32], sGroupSw[16];
+    __shared__ int sBigLo[16], sBigHi[16];
     __shared__ int sMaxRad;
     __shared__ unsigned long long sLive;
     __shared__ int sSliceDiffers;
@@ -1123,7 +1135,7 @@ __global__ __launch_bounds__(256) void k_ks_plan(FieldState* stGlobal, LayerPlan
     }
     if (tid == 0) { sMaxPassive = 0; sMaxRad = 0; sLive = 0ull; sSliceDiffers = 0; }
     if (tid < 32) sGroup[tid] = 0;
-    if (tid < 16) sGroupSw[tid] = 0;
+    if (tid < 16) { sGroupSw[tid] = 0; sBigLo[tid] = 0x7fffffff; sBigHi[tid] = 0; }
     __syncthreads();
     FieldState* st = &sSt;
     const int first = st->beamFirstInside;
@@ -1157,6 +1169,18 @@ __global__ __launch_bounds__(256) void k_ks_plan(FieldState* stGlobal, LayerPlan
         atomicMax(&sGroup[l % G], lfp);
         atomicMax(&sGroupSw[l % Gs], lfp);
         if (lfp > first) atomicAdd(&sLive, (unsigned long long)(lfp - first));
+        // the steps of the layer with a tile whose batch radius the sweep's first launch does not take (k_fill recorded the steps of
+        // every radius class; the batch radius of a class is known only here)
+        if (sweepMaxR >= 0 && layerMax <= kMaxSuperpR && layerMax > sweepMaxR) {
+            int lo = 0x7fffffff, hi = -1;                            // (one more round trip — unconditional loads, all in flight — only in a field with such radii)
+#pragma unroll
+            for (int i = 1; i <= kMaxSuperpR; ++i) {
+                const int a = p.classLo[i], b = p.classHi[i];
+                const bool big = hist[i] > 0 && effRad[i] > sweepMaxR;
+                lo = big ? min(lo, a) : lo; hi = big ? max(hi, b) : hi;
+            }
+            if (hi >= lo) { atomicMin(&sBigLo[l % Gb], lo); atomicMax(&sBigHi[l % Gb], hi + 1); }
+        }
     }
     __syncthreads();
     // Uniform-sigma field (water)? No tile saw two sigma^2 (k_fill) and every depositing (layer, step) has one over all its tiles.
@@ -1217,7 +1241,7 @@ __global__ __launch_bounds__(256) void k_ks_plan(FieldState* stGlobal, LayerPlan
         st->uniformField = (maybeUniform && !sSliceDiffers) ? 1 : 0;
         st->maxRadius = sMaxRad;
         for (int gI = 0; gI < 32; ++gI) st->groupPassive[gI] = sGroup[gI];
-        for (int gI = 0; gI < 16; ++gI) st->swGroupPassive[gI] = sGroupSw[gI];
+        for (int gI = 0; gI < 16; ++gI) { st->swGroupPassive[gI] = sGroupSw[gI]; st->swBigFirst[gI] = sBigLo[gI]; st->swBigPassive[gI] = sBigHi[gI]; }
         st->bevLo[0] = bevLo[0]; st->bevLo[1] = bevLo[1]; st->bevHi[0] = bevHi[0]; st->bevHi[1] = bevHi[1];
         st->liveSteps = (long long)sLive;
         st->packX0 = 0; st->packY0 = 0; st->packW = fc.bevW; st->packH = fc.bevH; st->slabFirst = first;

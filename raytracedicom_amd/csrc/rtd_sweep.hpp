@@ -26,9 +26,10 @@
 // a fixed order and the BEV dose stays bitwise reproducible like k_superpose_mfma's. Plain read-modify-write under the ticket (LDS
 // float atomics measured 2x slower), tile pitch 100 (conflict-free for the MFMA result layout). The groups' (and neighbouring
 // patches') tiles are summed by the LAST block of the step to arrive (agent-scope hand-off as in k_superpose_mfma's tree;
-// MI355X_MICROARCH.md "Correctness boundaries"), which writes the whole BEV slice, zeros included. Radii above 16 (reference limit:
-// 32) stay with k_superpose_mfma: the field's largest batch radius is known on the device (FieldState::maxRadius) and each of the two
-// kernels returns at once when the field is the other's.
+// MI355X_MICROARCH.md "Correctness boundaries"), which writes the whole BEV slice, zeros included. Tiles with a batch radius above 16
+// (reference limit: 32; a few deep steps of the upper layers in the fields that have them at all) are left out here: the second launch,
+// k_superpose_sweep_big (rtd_sweep_big.hpp), superposes exactly those and adds them to the slices; it returns at once when the
+// field's largest batch radius (FieldState::maxRadius) shows that there are none.
 // Measured and dropped (C3, parity-green): 16 waves per block that leave their T in LDS and, after a barrier, gather the rows of the
 // tile they own (no ticket; tile in registers): one block per CU, so nothing overlaps the gather phases — 0.51 ms against 0.35 ms.
 #pragma once
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(64 * kSwWaves, 4) void k_superpose_sweep(const floa
     const int nPg = nPXg * nPYg;
     const int k = fc.S - 1 - item % fc.S; item /= fc.S;
     const int p = item;
-    if (st->errorFlags || st->uniformField || st->maxRadius > kSwMaxR) return;   // radius overflow / water field / a field of k_superpose_mfma
+    if (st->errorFlags || st->uniformField) return;                  // radius overflow / water field
     const int first = st->beamFirstInside, calcPassive = st->firstCalculatedPassive;
     if (k < first || k >= calcPassive) return;
     // the rectangle of rays that carry dose anywhere in the field, cut into 64 x 64 patches from its own corner
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(64 * kSwWaves, 4) void k_superpose_sweep(const floa
             const int l = sLay[j];
             const int own = tileRad[((size_t)l * S + k) * nTiles + ty * fc.tilesX + tx];
             if (own <= kMaxSuperpR) r = layers[l].effRad[own];       // (0xFF: not classified; overflow is reported through errorFlags)
-            if (r > kSwMaxR) r = -1;                                 // cannot happen when maxRadius <= kSwMaxR
+            if (r > kSwMaxR) r = -1;                                 // the second launch's
         }
         sEff[i] = (signed char)r;
     }

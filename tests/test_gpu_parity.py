@@ -228,25 +228,28 @@ def test_spot_map_taller_than_the_lds_tile(orc, engine, synth):
 
 
 def test_c3_through_the_output_stationary_kernel(orc, engine, synth, ct512, monkeypatch):
-    """The bench field with k_superpose_sweep switched off (RTD_NO_SWEEP, read at field creation): k_superpose_mfma — the kernel that
-    takes the fields with batch radii above 16 — keeps its full-size parity evidence."""
+    """The bench field with the row sweep switched off (RTD_NO_SWEEP, read at field creation): k_superpose_mfma, round 2's kernel — kept
+    as a second implementation of the superposition that the sweep is compared with — keeps its full-size parity evidence."""
     monkeypatch.setenv("RTD_NO_SWEEP", "1")
     scn = scenarios.hetero_ct(synth, n=512, angles=[0.0], ct=ct512)
     _compare_field(orc, engine, scn, scn.beams[0])
 
 
 @pytest.mark.parametrize("spacing,want_big", [((0.5, 0.5), True), ((1.0, 1.0), False)])
-def test_general_superposition_kernel_is_chosen_on_the_device(orc, engine, synth, spacing, want_big):
-    """Rays 0.5 mm apart double the radii in pixels: the field's largest batch radius exceeds 16, k_superpose_sweep returns at once
-    and k_superpose_mfma writes the BEV dose (both are launched until a finished compute has told the host which one the field
-    needs). Same field object computed three times: first with both kernels in the stream, then with the one the hint names;
-    identical bits every time, and every intermediate against the oracle."""
+def test_large_radii_go_through_the_second_sweep_launch(orc, engine, synth, spacing, want_big):
+    """Rays 0.5 mm apart double the radii in pixels: batch radii up to the reference's limit of 32 (every level of
+    k_superpose_sweep_big and its vector row |dy| = 32 run). k_superpose_sweep superposes the tiles of radius <= 16 and writes the slices,
+    k_superpose_sweep_big adds the rest (launched until a finished compute has told the host that the field has none). Same field object
+    computed three times: first with what the host launches blind, then with what the hint names; identical bits every time, and every
+    intermediate against the oracle."""
     ct, _ = scenarios.hetero_phantom(96)
     scn = scenarios.hetero_ct(synth, n=96, spots=4, pitch=6.0, n_layers=3, angles=[0.0], steps=200, ct=ct)
     beam = scenarios.make_field(synth, 96, 256.0 / 96, (-128.0, -128.0, -106.0), 0.0, 4, 6.0, 3, 21, steps=200, ray_spacing=spacing, weight_lo=400.0)
     scn = scenarios.Scenario("rays %g mm" % spacing[0], synth, ct, scn.spacing, [beam])
     dose, ref, timing, info = _compare_field(orc, engine, scn, beam)
     assert (info["max_radius"] > 16) == want_big, info["max_radius"]
+    if want_big:
+        assert info["max_radius"] == 32
     n = scn.n_voxels
     with engine.Engine(0) as eng:
         eng.set_luts(synth)
@@ -264,12 +267,20 @@ def test_general_superposition_kernel_is_chosen_on_the_device(orc, engine, synth
         eng.device_free(d)
 
 
-def test_the_two_general_superposition_kernels_agree(orc, engine, synth, monkeypatch):
-    """k_superpose_sweep (source rows swept, T[|dy|][x] on the matrix cores) and k_superpose_mfma (output tiles visited) on the same
-    heterogeneous field with 17 layers: BEV doses within 1e-5 of each other relative to the maximum region (same weights up to the
-    series threshold, different order of the sums), identical support, both within the parity bar of the oracle."""
-    ct, _ = scenarios.hetero_phantom(128)
-    scn = scenarios.hetero_ct(synth, n=128, spots=7, pitch=6.0, n_layers=17, angles=[20.0], source_dist=(1900.0, 2300.0), ct=ct)
+@pytest.mark.parametrize("case", ["radii <= 16", "radii up to 32"])
+def test_the_two_general_superposition_kernels_agree(orc, engine, synth, monkeypatch, case):
+    """The row sweep (k_superpose_sweep + k_superpose_sweep_big: source rows swept, T[|dy|][x] on the matrix cores) and k_superpose_mfma
+    (output tiles visited) on the same heterogeneous field — 17 layers with radii within the first launch's reach, and 0.5 mm rays
+    with radii up to 32, where the second launch adds the tiles of radius 17 .. 32: BEV doses within 1e-5 of each other relative to
+    the maximum region (same weights up to the series threshold, different order of the sums), identical support, both within the parity
+    bar of the oracle."""
+    if case == "radii <= 16":
+        ct, _ = scenarios.hetero_phantom(128)
+        scn = scenarios.hetero_ct(synth, n=128, spots=7, pitch=6.0, n_layers=17, angles=[20.0], source_dist=(1900.0, 2300.0), ct=ct)
+    else:
+        ct, _ = scenarios.hetero_phantom(96)
+        beam = scenarios.make_field(synth, 96, 256.0 / 96, (-128.0, -128.0, -106.0), 0.0, 5, 6.0, 4, 23, steps=200, ray_spacing=(0.5, 0.5), weight_lo=400.0)
+        scn = scenarios.Scenario("rays 0.5 mm", synth, ct, (256.0 / 96,) * 3, [beam])
     ref = np.zeros_like(scn.ct)
     of = orc.run_field(scn, scn.beams[0], ref, keep_layers=True)
     W, H, L = of.info["ray_dims"]
@@ -281,6 +292,7 @@ def test_the_two_general_superposition_kernels_agree(orc, engine, synth, monkeyp
         else:
             monkeypatch.setenv("RTD_NO_SWEEP", env)
         eng, fld, dose, timing, info, d_dose = _run_engine(engine, scn, scn.beams[0])
+        assert (info["max_radius"] > 16) == (case != "radii <= 16")
         try:
             res[name] = (fld.fetch("bev").reshape(-1, H + 64, W + 64).copy(), dose.copy())
         finally:

@@ -34,19 +34,21 @@ def test_bitwise_reproducible(engine, synth):
 
 
 def test_exact_linearity_in_spot_weights(engine, synth):
-    """Scaling every spot weight by 2 (exact in binary) scales every stage, hence the dose, by exactly 2 when the
-    ray-weight cut-off cannot change the live set (RAY_WEIGHT_CUTOFF = 0)."""
+    """Scaling every spot weight by 4 (exact in binary) scales every stage, hence the dose, by exactly 4 when the
+    ray-weight cut-off cannot change the live set (RAY_WEIGHT_CUTOFF = 0). (A power of FOUR: the row sweep folds the square root of a
+    source's dose into both factors of its patch, (sqrt(d) e_i)(sqrt(d) e_j) — exactly scalable only when the root of the factor is a
+    power of two.)"""
     ct, _ = scenarios.hetero_phantom(96)
     scn = scenarios.hetero_ct(synth, n=96, spots=5, pitch=8.0, n_layers=3, angles=[0.0], ct=ct)
     opt = abi.default_options()
     opt.ray_weight_cutoff = 0.0
     d1 = _dose(engine, scn, options=opt)
     b = scn.beams[0]
-    b2 = scenarios.BeamSettings(b.spotWeights * np.float32(2.0), b.beamEnergies, b.spotSigmas, b.raySpacing, b.tracerSteps, b.sourceDist,
+    b2 = scenarios.BeamSettings(b.spotWeights * np.float32(4.0), b.beamEnergies, b.spotSigmas, b.raySpacing, b.tracerSteps, b.sourceDist,
                                 b.spotIdxToGantry, b.gantryToImIdx, b.gantryToDoseIdx)
     d2 = _dose(engine, scn, beams=[b2], options=opt)
     assert d1.max() > 0
-    np.testing.assert_array_equal(d2, d1 * np.float32(2.0))
+    np.testing.assert_array_equal(d2, d1 * np.float32(4.0))
 
 
 def test_c2_reference_water_cube_full_size(orc, engine, synth):
