@@ -84,11 +84,12 @@ def main():
                     help="N=1 only, not the default: launch consecutive plans round-robin on this many HIP streams, so the kernels of "
                          "independent plans overlap (throughput of a multi-field plan on one GPU; per-kernel durations in stage_ms / "
                          "roofline then include the sharing of the GPU)")
-    ap.add_argument("--secondary", action="store_true",
-                    help="also run the secondary 3-stream throughput leg (throughput_3_streams). Not in the default run: its overlapped kernels "
-                         "would enter the per-kernel averages of a `rocprofv3 --stats -- python bench.py` beside the timed single-stream loop, "
-                         "whose kernel durations are what `roofline` reports")
-    ap.add_argument("--no-secondary", action="store_true", help=argparse.SUPPRESS)   # (accepted for older command lines: the default now)
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary leg (throughput_streams: the same steps once more with consecutive plans on 4 HIP streams). "
+                         "profiles/collect.sh passes this: the leg's overlapped kernels would enter the per-kernel averages of a "
+                         "`rocprofv3 --stats -- python bench.py` beside the timed single-stream loop, whose kernel durations are what `roofline` reports")
+    ap.add_argument("--secondary", action="store_true", help=argparse.SUPPRESS)      # (accepted for older command lines: the default now)
+    ap.add_argument("--secondary-streams", type=int, default=4, help="HIP streams of the secondary leg")
     ap.add_argument("--exchange-selftest", action="store_true",
                     help="N=1 only: run the N>1 code path (process group, all-gather, fused slab transfer) with a world of one rank — "
                          "exercises the RCCL calls on a one-GPU box; not a benchmark mode")
@@ -298,12 +299,13 @@ def main():
         dist.all_reduce(tl, op=dist.ReduceOp.MAX)
         ms_latency = float(tl.item())
 
-    # ---- secondary figure (N=1, default run only): throughput with consecutive plans on 3 HIP streams, so that the tail of one plan's
-    #      superposition overlaps the next plan's tracer / fill. NOT the headline: `value`, stage_ms and the roofline come from the
-    #      single-stream loop above, where a kernel's duration is that of the kernel alone. ----
+    # ---- secondary figure (N=1): throughput with consecutive plans on 4 HIP streams — independent plans (a plan's fields, or a queue
+    #      of patients) overlap: the latency-bound launches of one (scan, plans, the tails of fill / superposition / transfer) run beside
+    #      the issue-bound kernels of another. NOT the headline: `value`, stage_ms and the roofline come from the single-stream loop
+    #      above, where a kernel's duration is that of the kernel alone and a step is one plan's latency chain. ----
     multi = None
-    if not xchg and n_streams == 1 and args.secondary:
-        ns = 3
+    if not xchg and n_streams == 1 and not args.no_secondary:
+        ns = max(2, args.secondary_streams)
         ss = [torch.cuda.Stream(device=dev) for _ in range(ns)]
         fl = [eng.create_field(beam, scn.dims) for _ in range(ns)]
         vols = [torch.zeros((n, n, n), dtype=torch.float32, device=dev) for _ in range(ns)]
@@ -331,7 +333,7 @@ def main():
         same = all(torch.equal(v, vols[0]) for v in vols[1:])
         eng.set_stream(main_stream.cuda_stream)
         multi = {"streams": ns, "ms_per_step": round(1000.0 * m_el / args.steps, 4), "mvoxels_s": round(n_vox * args.steps / m_el / 1e6, 1),
-                 "volumes_identical": bool(same)}
+                 "volumes_identical": bool(same)}       # (+ path_frac_of_hbm_peak below, once the algorithmic bytes are known)
         for f in fl:
             f.destroy()
         del vols
@@ -454,7 +456,7 @@ def main():
                                     "transfer rates %s ps per 1000 voxels" % (world, ex.cap / 1e6, ex.axis, ex.ranges, ex.heads_us, ex.rates_ps_kvox))},
             "ms_plan": round(ms_per_step, 4),
             "ms_plan_latency": round(ms_latency, 4),
-            "throughput_3_streams": multi,
+            "throughput_streams": multi,
             "reduce_check_rel_err": reduce_check, "clear_check": clear_check, "assembled_check": assembled_check,
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "algorithmic_bytes": alg,
@@ -462,6 +464,11 @@ def main():
             "path_frac_of_hbm_peak": round(alg["total"] / (stage_ms["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": roof,
         }
+        if multi is not None:       # the pipelined leg against the same algorithmic bytes (wall time of its steps, not a stage sum)
+            multi["path_frac_of_hbm_peak"] = round(alg["total"] / (multi["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            multi["what"] = ("the same %d plans once more, consecutive plans round-robin on %d HIP streams (one field object and one dose volume "
+                             "each): independent plans overlap on the GPU; not the headline — a plan's own kernels are a latency chain, which "
+                             "`value` and `ms_plan_latency` report" % (args.steps, multi["streams"]))
         if oracle is not None:
             # ---- CPU baseline: the oracle (kind "port") on this host. Headline sample: 4 fields of the bench workload on ncpu threads. ----
             cpu_dose = np.zeros_like(scn.ct)

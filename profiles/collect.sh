@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --steps 20 --warmup 3 --no-cpu"   # (the optional 3-stream leg, --secondary, would overlap kernels: it is not part of the default run)
+BENCH="python3 $R/bench.py --steps 20 --warmup 3 --no-cpu --no-secondary"   # (without the 4-stream leg: its overlapped kernels would enter the per-kernel averages)
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- $BENCH > $OUT/stats.log 2>&1 || echo "stats pass failed"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o p --output-format csv -- $BENCH > $OUT/fetch.log 2>&1 || echo "fetch pass failed"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o p --output-format csv -- $BENCH > $OUT/write.log 2>&1 || echo "write pass failed"

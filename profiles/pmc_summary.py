@@ -40,7 +40,8 @@ def traffic(paths):
         out["k_superpose"] = dict(out[dom], kernel="rtd::" + dom)
         # issue counters of the dominant kernel, when the SQ passes are given too (bench.py: roofline.issue_cycle_frac, mfma_tflops)
         for k, d in collect(paths).items():
-            if dom not in k: continue
+            m = re.search(r"rtd::(k_\w+)", k)
+            if not m or m.group(1) != dom: continue     # (exactly: k_superpose_sweep_big is another kernel)
             mean = lambda c: sum(d[c]) / len(d[c]) if c in d else None
             if mean("SQ_INSTS_MFMA"): out["k_superpose"]["mfma_insts_per_launch"] = int(mean("SQ_INSTS_MFMA"))
             if mean("SQ_INSTS_VALU"): out["k_superpose"]["valu_insts_per_launch"] = int(mean("SQ_INSTS_VALU"))
