@@ -639,7 +639,8 @@ static int createField(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dim
            (size_t)S * f->swPX * f->swPY * f->swGroups * kSwSlot * sizeof(float) > ((size_t)2 << 30)) --f->swGroups;
     f->sig.Gs = (size_t)f->swGroups;
     f->bgGroups = std::max(1, std::min(kBgMaxGroups, L));
-    if ((size_t)S * f->swPX * f->swPY * f->bgGroups * kBgSlot * sizeof(float) > ((size_t)1 << 30)) f->bgGroups = 1;
+    while (f->bgGroups > std::max(1, (L + kSwMaxLay - 1) / kSwMaxLay) &&       // (a group holds at most kSwMaxLay layers: L <= 256 needs up to 4)
+           (size_t)S * f->swPX * f->swPY * f->bgGroups * kBgSlot * sizeof(float) > ((size_t)1 << 30)) --f->bgGroups;
     if (f->sweepEnabled) f->sig.G = 0;      // (the partial BEV buffers of k_superpose_mfma exist only without the sweep)
     rtd_field_impl* husk = nullptr;
     for (size_t i = 0; i < h->fieldCache.size(); ++i)

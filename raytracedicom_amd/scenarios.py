@@ -180,7 +180,7 @@ def hetero_phantom(n, seed=7, noise=20.0):
 
 
 def hetero_ct(luts, n=512, n_fields=1, spots=10, pitch=6.0, n_layers=20, seed=99, source_dist=(math.inf, math.inf),
-              angles=None, steps=512, ct=None, gantry_rot=None):
+              angles=None, steps=512, ct=None, gantry_rot=None, ray_spacing=(1.0, 1.0)):
     """C3 (n=512, 1 field), C4 (n=512, 4 fields at 0/90/180/270), C5 (n=768, 8 fields every 45 deg)."""
     if ct is None:
         ct, voxel = hetero_phantom(n)
@@ -189,7 +189,7 @@ def hetero_ct(luts, n=512, n_fields=1, spots=10, pitch=6.0, n_layers=20, seed=99
     origin = (-128.0, -128.0, -106.0)
     if angles is None:
         angles = [i * 360.0 / n_fields for i in range(n_fields)]
-    beams = [make_field(luts, n, voxel, origin, a, spots, pitch, n_layers, seed + 17 * i, source_dist, steps, gantry_rot=gantry_rot)
+    beams = [make_field(luts, n, voxel, origin, a, spots, pitch, n_layers, seed + 17 * i, source_dist, steps, ray_spacing=ray_spacing, gantry_rot=gantry_rot)
              for i, a in enumerate(angles)]
     snx, sny = (spots, spots) if np.isscalar(spots) else spots
     return Scenario("hetero%d_F%d" % (n, len(beams)), luts, ct, (voxel,) * 3, beams,

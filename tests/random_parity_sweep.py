@@ -22,12 +22,31 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     deg = float(rng.choice([0.0, 13.0, 45.0, 90.0, 141.0, 180.0, 270.0, 300.0]))
     dist = (math.inf, math.inf) if rng.random() < 0.4 else (float(rng.uniform(900, 3000)), float(rng.uniform(900, 3000)))
     steps = int(rng.choice([97, 200, 256, 333, 512, 600]))
-    scn = scenarios.hetero_ct(synth, n=n, spots=spots, pitch=pitch, n_layers=n_layers, angles=[deg], source_dist=dist, steps=steps, ct=ct)
+    # (drawn last, so the scenarios of the earlier sweeps keep their seeds) a quarter of the scenarios with finer rays: batch radii
+    # beyond 16 pixels, the second sweep launch
+    rs = float(rng.choice([1.0, 1.0, 1.0, 0.75, 0.6])) if len(sys.argv) > 3 and sys.argv[3] == "rays" else 1.0
+    if rs != 1.0:
+        spots = min(spots, 6)
+    scn = scenarios.hetero_ct(synth, n=n, spots=spots, pitch=pitch, n_layers=n_layers, angles=[deg], source_dist=dist, steps=steps, ct=ct,
+                              ray_spacing=(rs, rs))
     try:
         T._compare_field(orc, engine, scn, scn.beams[0])
+    except RuntimeError as e:
+        if "larger than allowed" not in str(e):
+            raise
+        print("seed", seed, "radius overflow reported (a class beyond 32: the reference throws there too), rays", rs)
+        continue
     except AssertionError as e:
         import traceback
         tb = traceback.format_exc()
+        if "of.status == 0" in tb:             # the oracle stopped (a radius class beyond 32, where the reference throws): the engine must report it too
+            try:
+                T._run_engine(engine, scn, scn.beams[0])
+                raise SystemExit("seed %d: the oracle reports an error, the engine does not" % seed)
+            except RuntimeError as e2:
+                assert "larger than allowed" in str(e2), str(e2)
+            print("seed", seed, "radius overflow: oracle and engine both report it, rays", rs)
+            continue
         if "(1.0, 0, 0.0)" in str(e):          # pencil too thin for the gamma sampling grid: every other comparison passed
             print("seed", seed, "gamma had no voxels to evaluate (all other comparisons passed)")
         elif "max rel err" in str(e):
@@ -39,5 +58,5 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         else:
             raise
     n_ok += 1
-    print("seed", seed, "ok", n, spots, pitch, n_layers, deg, steps, flush=True)
+    print("seed", seed, "ok", n, spots, pitch, n_layers, deg, steps, rs, flush=True)
 print("all", n_ok, "ok")
