@@ -25,6 +25,7 @@
 #include "rtd_kernels.hpp"
 #include "rtd_sweep.hpp"
 #include "rtd_sweep_big.hpp"
+#include "rtd_uniform.hpp"
 
 using namespace rtd;
 
@@ -50,7 +51,7 @@ struct rtd_handle_impl {
     int numCUs = 256;             // compute units of the device (grid size of the grid-stride kernels)
     bool scanLdsSet = false;      // dynamic-LDS cap of k_trace_scan raised (once per handle)
     size_t traceTLds = 0;         // dynamic-LDS cap set for k_trace_sample_t so far
-    size_t uniLds = 0;            // ... for k_superpose_uniform
+    size_t uni3Lds = 0;           // ... for k_superpose_uniform3
     bool sweepLdsSet = false;     // ... for k_superpose_sweep
     bool sweepBigLdsSet = false;  // ... for k_superpose_sweep_big
     unsigned inputEpoch = 0;      // bumped whenever CT, LUTs or options change (fields re-test what they learned about their input)
@@ -886,13 +887,28 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
         // A field with one sigma per slice (water) is superposed as a separable convolution; whether this field is one is known
         // on the device only (FieldState::uniformField): the launch returns at once otherwise, k_superpose_mfma below when it is.
         // A small persistent grid, so that the empty launch of a heterogeneous field costs next to nothing.
-        const size_t uLds = (size_t)(fc.H + kUniTmpPad) * kUniTmpPitch * sizeof(float);   // the x-pass result with its zero rows
-        if (h->uniLds < uLds) {
-            RTD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_superpose_uniform), hipFuncAttributeMaxDynamicSharedMemorySize, (int)uLds));
-            h->uniLds = uLds;
+        const int nYB = (fc.bevH + 15) / 16;
+        const size_t u3Lds = (size_t)2 * fc.H * (fc.W + 16) * sizeof(float);
+        const bool u3 = fc.W <= 16 * (kU2XB - 4) && nYB <= 16 && u3Lds <= 150 * 1024 && (size_t)fc.W * fc.H / 4 <= (size_t)kU3MaxV4 * 64 * nYB &&
+                        std::getenv("RTD_UNIFORM_V2") == nullptr;
+        if (u3) {
+            // (rtd_uniform.hpp: one block per slice, its layers staged in two LDS buffers a layer ahead)
+            if (h->uni3Lds < u3Lds) {
+                RTD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_superpose_uniform3<768>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)u3Lds));
+                RTD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_superpose_uniform3<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)u3Lds));
+                h->uni3Lds = u3Lds;
+            }
+            auto launchU3 = [&](auto kern) {
+                launchK(kern, dim3((unsigned)fc.S), dim3(64 * nYB), u3Lds, s, ksStart, knownUniform ? f->ev[5] : nullptr, (const float*)f->dIdd,
+                        (const LayerPlan*)f->dLayers, (const FieldState*)f->dState, fc, (const unsigned int*)f->dSigMin, (const float*)f->dStepTab, f->dBev);
+            };
+            if (nYB <= 12) launchU3(k_superpose_uniform3<768>); else launchU3(k_superpose_uniform3<1024>);
+        } else {
+            // (rtd_uniform.hpp: one wave per 16 rows x 192 columns of a slice, no staging, no barrier in its loop)
+            const int nXS = (fc.bevW + 16 * kU2XB - 1) / (16 * kU2XB), nParts = ((fc.bevH + 15) / 16 + 3) / 4;
+            launchK(k_superpose_uniform2, dim3((unsigned)(fc.S * nXS * nParts)), dim3(256), 0, s, ksStart, knownUniform ? f->ev[5] : nullptr, (const float*)f->dIdd,
+                    (const LayerPlan*)f->dLayers, (const FieldState*)f->dState, fc, (const unsigned int*)f->dSigMin, (const float*)f->dStepTab, f->dBev, nXS);
         }
-        launchK(k_superpose_uniform, dim3((unsigned)h->numCUs * 2), dim3(256), uLds, s, ksStart, knownUniform ? f->ev[5] : nullptr, (const float*)f->dIdd, (const LayerPlan*)f->dLayers,
-                (const FieldState*)f->dState, fc, (const unsigned int*)f->dSigMin, (const float*)f->dStepTab, f->dBev);
         ksStart = nullptr;
     }
     // The general superposition is the row sweep in two launches: k_superpose_sweep for the sources whose batch radius is within its

@@ -71,7 +71,7 @@ struct FieldState {
     int packX0, packY0, packW, packH, slabFirst;
     // Uniform-sigma fields (water): k_fill raises nonUniform when the live rays of a (layer, step, tile) differ in sigma^2; k_ks_plan
     // sets uniformField when no tile did and every depositing (layer, step) slice has ONE sigma^2 over all its tiles — the
-    // superposition of such a slice is a separable convolution (k_superpose_uniform) and k_superpose_mfma stands aside.
+    // superposition of such a slice is a separable convolution (rtd_uniform.hpp) and the general superposition stands aside.
     int nonUniform, uniformField;
     unsigned short fillItems[2 * 256];      // (layer << 1 | role) of k_fill's walks by descending cost (k_plan), for its block placement
     unsigned char tileOrder[kKsMaxOrder];   // superposition dispatch order of the output tiles: most source rays in reach first
@@ -1413,7 +1413,7 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
     const int tX = tile % nTX, tY = tile / nTX;
     const int first = st->beamFirstInside, calcPassive = st->firstCalculatedPassive;
     if (st->errorFlags) return;                                      // radius overflow: the reference throws before any superposition (kernel_wrapper.cu:965)
-    if (st->uniformField) return;                                    // one sigma per slice: k_superpose_uniform has written the BEV dose
+    if (st->uniformField) return;                                    // one sigma per slice: the separable kernel (rtd_uniform.hpp) has written the BEV dose
     if (st->maxRadius <= sweepMaxR) return;                          // every batch radius within k_superpose_sweep's reach: it writes the BEV dose
     if (k < 0 || k < first || k >= calcPassive) return;
     const int li = lane & 15, kq = lane >> 4;                         // MFMA 16x16x4: A[i=li][k=kq], B[k=kq][j=li]
@@ -1726,195 +1726,10 @@ __global__ __launch_bounds__(64 * kKsSplit, 7) void k_superpose_mfma(const float
 }
 
 // ------------------------------------------------------------------------------------------------
-// K7u: the superposition of a field whose every (layer, step) slice has ONE sigma over its live rays — a water phantom, the
-// reference's own WATER_CUBE_TEST. There the per-voxel-sigma patches of kernelSuperposition (kernel_wrapper.cuh:432-489) add up to
-// a separable convolution of the slice with that layer's pixel-integrated Gaussian: an x pass and a y pass, 2 (2 rho + 1)
-// multiply-adds per pixel instead of (2 rho + 1)^2 — what the reference's CPU path does (cpu_convolution_1d.cpp: xConvCpuScat +
-// yConvCpu), and the HIP result is checked against exactly that code (tests/test_gpu_parity.py, C1). Whether a field qualifies
-// is decided on the device (k_fill / k_ks_plan: FieldState::uniformField); this launch returns at once otherwise, and
-// k_superpose_mfma does when it does not.
-// Work item = (slice k, strip of 32 BEV columns), a persistent grid strides over them. Both passes are banded Toeplitz products on
-// the matrix cores (v_mfma_f32_16x16x4_f32): with w[u] = e[|u - rho|] (the same pixel integrals as k_superpose_mfma: Taylor series
-// for sigma >= 1.4 px, erf differences below; zeros around it),
-//   x pass  tmp[r][c]  = sum_k in[r][k] * w[k - c]      A = 32 ray rows at a time staged in LDS, B = the Toeplitz band
-//   y pass  out[y][c]  = sum_k w[k - y] * tmp[k][c]     A = the band, B = tmp in LDS (zero rows above and below)
-// 16 + 2 rho + 1 values of k per 16 x 16 block. The item's depositing layers are listed first (their plan records fetched in
-// parallel, not one dependent chain per layer). Per layer and 32-row chunk a wave stages 8 rows (its lanes the staged columns lane,
-// lane + 64: 16 loads in flight, no per-element index arithmetic; the next chunk — of this or the next layer — is fetched into
-// registers while this one is on the matrix cores, two LDS buffers alternate, one barrier per chunk) and owns one block of the
-// chunk's x pass (two accumulation chains over alternate k steps); in the y pass the band operand is the same for every block, so a wave runs its up to 8 blocks as
-// independent chains behind one band load per k step. The layers are added in ascending order: reproducible.
-// Per-phase clock stamps (one wave per block): y pass 31 %, x pass 22 %, requesting the next chunk 21 % and moving it to LDS 16 %
-// of the time — in front of each matrix LOOP the compiler waits for every load in flight, so the requests do not hide behind the
-// matrix work as intended (unrolling the loops to avoid that made the code slower: 0.45 and 2.0 ms); the matrix cores are busy 19 %.
-// (History on the reference's water cube, where k_superpose_mfma takes 1.18 ms: vector-ALU version with a sliding window 0.71 ms
-// and first matrix version 0.67 ms — both spent their time in a staging loop of one dependent load per trip; everything staged
-// into registers and every loop unrolled: 1.2 - 1.5 ms — instruction fetch, 14 k lines of code.)
-constexpr int kUniMaxBevH = 256;                                     // 16 row blocks x 2 column blocks = 8 accumulator tiles per wave
-constexpr int kUniInPitch = 101;                                     // row pitch of the staged chunk: >= 32 + 2 rho + 4 columns, odd
-constexpr int kUniTmpPad = 164;                                      // rows of the x-pass result beside the H ray rows: 64 above, the y pass's reach below
-constexpr int kUniTmpPitch = 33;                                     // (odd: the four k rows of a B operand fall into different banks)
-__global__ __launch_bounds__(256) void k_superpose_uniform(const float* __restrict__ bevIdd, const LayerPlan* __restrict__ layers,
-                                                            const FieldState* __restrict__ st, FieldConst fc,
-                                                            const unsigned int* __restrict__ sigMin, const float* __restrict__ stepTab,
-                                                            float* __restrict__ bevDose) {
-    if (!st->uniformField || st->errorFlags) return;
-    extern __shared__ float sTmp[];                                  // [64 + H + 100][33]: x-pass result, zero rows above and below
-    __shared__ float sIn[2 * 32 * kUniInPitch];                      // two buffers of a chunk's ray rows, columns x0 ...
-    __shared__ float sWp[16 + 2 * kMaxSuperpR + 8 + 16];             // w[u] at [16 + u], zeros on both sides
-    __shared__ int sLay[256], sRho[256], sCount[4];
-    __shared__ float sRs[256];
-    const int t = threadIdx.x;
-    const int wv = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, li = lane & 15, kq = lane >> 4;
-    const int W = fc.W, H = fc.H;
-    const int first = st->beamFirstInside, nSlices = st->firstCalculatedPassive - first;
-    const int nStrips = (fc.bevW + 31) / 32;
-    const int nTilesY = 2 * ((fc.bevH + 15) / 16);                   // 16 x 16 output blocks of a strip (<= 32)
-    const size_t memStep = (size_t)W * H;
-    for (int i = t; i < (H + kUniTmpPad) * kUniTmpPitch; i += 256) sTmp[i] = 0.0f;   // (the x pass only ever writes rows [64, 64 + H))
-    __syncthreads();
-    for (int item = blockIdx.x; item < nStrips * nSlices; item += gridDim.x) {
-        const int k = first + item / nStrips, s = item % nStrips;
-        // ---- the item's depositing layers, ascending, with their 1/sigma and batch radius (thread l looks at layer l) ----
-        {
-            bool on = false; float rs = 0.0f; int rho = 0;
-            if (t < fc.L && k < layers[t].layerFirstPassive) {
-                const unsigned int bits = sigMin[(size_t)t * fc.S + k];
-                if (bits != 0x7f800000u) {                            // (+inf as stored by the reset: no live ray in this slice)
-                    const float sig2 = __uint_as_float(bits);
-                    const float sqrt2 = 1.41421356f;
-                    // 1/sigma of the slice's rays with k_fill's operations (same bits as its per-ray values); class and batch radius as there
-                    rs = stepTab[2 * k] * __builtin_amdgcn_rcpf(sqrt2 * (__builtin_amdgcn_sqrtf(sig2) + 0.21f));
-                    const float minRs = stepTab[2 * k] / (sqrt2 * (sqrtf(sig2) + 0.21f));
-                    int cls = f2iSat(fc.ksSigmaCutoff / (sqrtf(2.0f) * minRs) + 0.5f);
-                    cls = cls > kMaxSuperpR ? kMaxSuperpR : (cls < 0 ? 0 : cls);
-                    rho = layers[t].effRad[cls];
-                    on = true;
-                }
-            }
-            const unsigned long long mask = __ballot(on);
-            if (lane == 0) sCount[wv] = __popcll(mask);
-            __syncthreads();                                         // (also: the previous item is done with the lists)
-            int pos = __popcll(mask & ((1ull << lane) - 1ull));
-            for (int w2 = 0; w2 < wv; ++w2) pos += sCount[w2];
-            if (on) { sLay[pos] = t; sRho[pos] = rho; sRs[pos] = rs; }
-            __syncthreads();
-        }
-        const int nA = sCount[0] + sCount[1] + sCount[2] + sCount[3];
-        f32x4 acc[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) acc[q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        // Chunk (layer a of the list, ray rows r0 ...) into registers: wave wv takes rows r0 + wv, r0 + wv + 4, ... (8 per wave), its
-        // lanes the staged columns lane and lane + 64 (staged column c <-> ray column x0 + c): 16 loads in flight, no per-element
-        // index arithmetic.
-        float va[8], vb[8];
-        bool preOkA = false, preOkB = false;
-        int preR0 = 0;
-        auto fetchChunk = [&](int a, int r0) {
-            const int rho = sRho[a], nC = 32 + ((2 * rho + 1 + 3) & ~3), x0 = 32 * s - 32 - rho;
-            const int xa = x0 + lane, xb = xa + 64;
-            const bool okA = lane < nC && xa >= 0 && xa < W, okB = lane + 64 < nC && xb >= 0 && xb < W;
-            const int ia = okA ? xa : 0, ib = okB ? xb : 0;           // (a valid column for the lanes that load nothing)
-            const float* __restrict__ idd = bevIdd + ((size_t)sLay[a] * fc.S + k) * memStep;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int y = r0 + wv + 4 * i;
-                const size_t ro = (size_t)(y < H ? y : 0) * W;
-                va[i] = idd[ro + ia]; vb[i] = idd[ro + ib];           // (not touched here: the values are masked when they go to LDS —
-            }                                                         //  a select on them would wait for the loads on the spot)
-            preOkA = okA; preOkB = okB; preR0 = r0;
-        };
-        int bufSel = 0;
-        if (nA > 0) fetchChunk(0, 0);
-        for (int a = 0; a < nA; ++a) {
-            const int rho = sRho[a];
-            const float rs = sRs[a];
-            const int nU = (2 * rho + 1 + 3) & ~3, nC = 32 + nU;     // band length padded to whole k steps; staged columns
-            if (t < 16 + nU + 16) {
-                float w = 0.0f;
-                const int u = t - 16;
-                if (u >= 0 && u <= 2 * rho) {
-                    const int ii = u < rho ? rho - u : u - rho;
-                    if (rs <= 0.5f) {                                 // Taylor series of the pixel integral (see k_superpose_mfma)
-                        const float h2 = rs * rs, h4 = h2 * h2;
-                        const float k1 = h2 * (1.0f / 24.0f), k2 = h4 * (1.0f / 1920.0f), k3 = h4 * h2 * (1.0f / 322560.0f);
-                        const float c0 = 1.0f - 2.0f * k1 + 12.0f * k2 - 120.0f * k3;
-                        const float c1 = (4.0f * k1 - 48.0f * k2 + 720.0f * k3) * h2;
-                        const float c2 = (16.0f * k2 - 480.0f * k3) * h4;
-                        const float c3 = 64.0f * k3 * (h4 * h2);
-                        const float wq = (float)(ii * ii);
-                        const float gq = 0.5641895835f * rs * __builtin_amdgcn_exp2f(-1.4426950409f * h2 * wq);
-                        w = gq * __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(c3, wq, c2), wq, c1), wq, c0);
-                    } else {
-                        w = ii == 0 ? erff(rs * 0.5f) : 0.5f * (erff(rs * ((float)ii + 0.5f)) - erff(rs * ((float)ii - 0.5f)));
-                    }
-                }
-                sWp[t] = w;
-            }
-            // ---- x pass, 32 ray rows at a time. The chunk that is about to be used sits in registers (fetched while the previous
-            //      chunk — or the previous layer's y pass — was on the matrix cores): registers -> LDS buffer, barrier, fetch the
-            //      next chunk, matrix work on this one. One barrier per chunk; the two LDS buffers alternate. ----
-            const int rb = wv >> 1, cb = wv & 1;
-            for (int r0 = 0; r0 < H; r0 += 32) {
-                float* buf = sIn + (size_t)bufSel * (32 * kUniInPitch);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    float* d0 = buf + (size_t)(wv + 4 * i) * kUniInPitch + lane;
-                    const bool rowIn = preR0 + wv + 4 * i < H;
-                    d0[0] = (preOkA && rowIn) ? va[i] : 0.0f;
-                    if (lane + 64 < nC) d0[64] = (preOkB && rowIn) ? vb[i] : 0.0f;
-                }
-                ldsBarrier();                                        // chunk and weights visible; the other buffer's readers are past it
-                if (r0 + 32 < H) fetchChunk(a, r0 + 32); else if (a + 1 < nA) fetchChunk(a + 1, 0);
-                // this wave's block of the chunk (row half rb, column half cb), two chains over alternate k steps
-                f32x4 d0 = {0.0f, 0.0f, 0.0f, 0.0f}, d1 = {0.0f, 0.0f, 0.0f, 0.0f};
-                const float* aRow = buf + (size_t)(16 * rb + li) * kUniInPitch + 16 * cb + kq;
-                const float* bw = &sWp[16 + kq - li];
-                int kk0 = 0;
-                for (; kk0 + 8 <= 16 + nU; kk0 += 8) {
-                    const float a0 = aRow[kk0], b0 = bw[kk0], a1 = aRow[kk0 + 4], b1 = bw[kk0 + 4];
-                    d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, d0, 0, 0, 0);
-                    d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, d1, 0, 0, 0);
-                }
-                if (kk0 < 16 + nU) d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aRow[kk0], bw[kk0], d0, 0, 0, 0);
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int r = r0 + 16 * rb + 4 * kq + reg;
-                    if (r < H) sTmp[(size_t)(64 + r) * kUniTmpPitch + 16 * cb + li] = d0[reg] + d1[reg];
-                }
-                bufSel ^= 1;
-            }
-            ldsBarrier();
-            // ---- y pass: out[y] = sum_u w[u] tmp[y - 32 - rho + u] (tmp row y sits at 64 + y): blocks wv, wv + 4, ... of the strip ----
-            {
-                const float* aw = &sWp[16 + kq - li];
-                // block wv + 4 q = (row block (wv >> 1) + 2 q, column half wv & 1): one pointer per k step, the blocks at constant offsets
-                const float* bRow = sTmp + (size_t)(32 - rho + kq + 16 * (wv >> 1)) * kUniTmpPitch + 16 * (wv & 1) + li;
-                const int nQ = (nTilesY - wv + 3) >> 2;               // this wave's blocks (wave-uniform)
-                for (int kk0 = 0; kk0 < 16 + nU; kk0 += 4, bRow += 4 * kUniTmpPitch) {
-                    const float av = aw[kk0];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                        if (q < nQ) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bRow[(size_t)q * 32 * kUniTmpPitch], acc[q], 0, 0, 0);
-                }
-            }
-            ldsBarrier();                                            // this layer's weights and x-pass result are consumed
-        }
-        float* out = bevDose + (size_t)k * fc.bevW * fc.bevH;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int tIdx = wv + 4 * q;
-            if (tIdx < nTilesY) {
-                const int ox = 32 * s + 16 * (tIdx & 1) + li;
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int oy = 16 * (tIdx >> 1) + 4 * kq + reg;
-                    if (oy < fc.bevH && ox < fc.bevW) out[(size_t)oy * fc.bevW + ox] = acc[q][reg];
-                }
-            }
-        }
-    }
-}
+// K7u, the superposition of a field whose every (layer, step) slice has ONE sigma over its live rays (a water phantom, the reference's
+// own WATER_CUBE_TEST): rtd_uniform.hpp. Whether a field qualifies is decided on the device (k_fill / k_ks_plan:
+// FieldState::uniformField); that launch returns at once otherwise, and the general superposition does when it does.
+constexpr int kUniMaxBevH = 256;                                     // a slice has at most 16 row blocks of 16 rows
 
 // ------------------------------------------------------------------------------------------------
 // K8: fan -> dose-grid transfer = primTransfDiv (kernel_wrapper.cu:69-97). The reference copies the BEV slab

@@ -1,5 +1,5 @@
 """Random sweep of water fields on a GPU box (not collected by pytest): the device-side uniform-sigma detection and the separable
-superposition kernel (k_superpose_uniform) through tests/test_gpu_parity._compare_field — every intermediate, the BEV dose, the dose
+superposition kernel (rtd_uniform.hpp) through tests/test_gpu_parity._compare_field — every intermediate, the BEV dose, the dose
 and gamma against the CPU oracle — for seeded random water cubes (size, spots, pitch, layers, steps, homogeneous density); the field
 must report uniform_sigma = 1 when the beam is parallel, 0 when it diverges. Usage: FIRST_SEED END_SEED."""
 import os, sys, math

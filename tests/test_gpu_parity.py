@@ -491,9 +491,29 @@ def test_c1_bev_dose_against_the_reference_cpu_convolution(orc, engine, synth):
         eng.close()
 
 
+@pytest.mark.parametrize("case", ["slice staged in LDS", "wave per row block", "wide ray grid: two strips"])
+def test_uniform_sigma_kernels(orc, engine, synth, monkeypatch, case):
+    """The two separable-superposition kernels of rtd_uniform.hpp on water fields, every intermediate against the oracle:
+    k_superpose_uniform3 (one block per slice, layers staged in LDS: ray grids of up to 128 columns), k_superpose_uniform2 (one wave
+    per row block and strip of 192 columns, no staging: forced with RTD_UNIFORM_V2 on the same field, and chosen by the engine for a
+    ray grid of 192 columns, where a slice has two strips)."""
+    if case == "wave per row block":
+        monkeypatch.setenv("RTD_UNIFORM_V2", "1")
+    else:
+        monkeypatch.delenv("RTD_UNIFORM_V2", raising=False)
+    if case == "wide ray grid: two strips":
+        scn = scenarios.water_cube(synth, n=128, n_layers=3, spots=47, pitch=3.0)
+    else:
+        scn = scenarios.water_cube(synth, n=128, n_layers=4)
+    _, _, _, info = _compare_field(orc, engine, scn, scn.beams[0])
+    assert info["uniform_sigma"] == 1
+    if case == "wide ray grid: two strips":
+        assert info["ray_dims"][0] > 128
+
+
 def test_uniform_sigma_path_equals_the_general_superposition(orc, engine, synth, monkeypatch):
-    """A water field is superposed by k_superpose_uniform (one sigma per slice: separable convolution), decided on the device. With
-    the path disabled (RTD_NO_UNIFORM_PATH, read at field creation) the same field goes through k_superpose_mfma: both BEV doses agree
+    """A water field is superposed by the separable kernels of rtd_uniform.hpp (one sigma per slice), decided on the device. With
+    the path disabled (RTD_NO_UNIFORM_PATH, read at field creation) the same field goes through the row sweep: both BEV doses agree
     to rounding (same weights, different order of the sums), both are within the parity tolerance of the oracle, and the dose too.
     A beam that leaves the water (air gap in the CT) is NOT uniform and must take the general path by itself."""
     scn = scenarios.water_cube(synth, n=128, n_layers=3)
