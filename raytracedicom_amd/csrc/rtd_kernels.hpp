@@ -759,6 +759,7 @@ __global__ __launch_bounds__(1024) void k_plan_conv(const float* __restrict__ in
 // IEEE sqrt and division.
 
 constexpr int kFillBatch = 8;   // steps per batch: inputs fetched one batch ahead, one block barrier per batch
+constexpr int kFillSnakeRounds = 12;   // up to this many walks per CU the walks are dealt in rounds of alternating direction (k_fill's block placement)
 
 // NUCLEAR_CORR arguments of the fill (kernel_wrapper.cu:190-198). The reference constructs its fill parameters with a nuclear
 // memory step of 0 (:925), so every step of a ray overwrites the same voxel of the nuclear arrays (:367-373) and what remains
@@ -782,8 +783,7 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
                                                int* __restrict__ active, int nCU, long long* __restrict__ dbg, NucFill nuc,
                                                unsigned int* __restrict__ sigMin, unsigned int* __restrict__ sigMax, int trackUniform) {
     extern __shared__ float sLutF[];                                 // dose walk: the layer's two cumulative-IDD rows
-    // diagnostic build only (RTD_FILL_DEBUG): per block start / end clock, hardware id, item — no output value depends on it
-    const long long dbgT0 = dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
+    // diagnostic build only (RTD_FILL_DEBUG): per walk start / end clock, hardware id, item — no output value depends on it
     __shared__ float sSig[2][kFillBatch][256];                       // sigma walk: [buffer][step][ray] sigmaSq of the rays with a finite 1/sigma (-1: none)
     __shared__ unsigned long long sDoseMask[2][kFillBatch][4];       // dose walk: [buffer][step][wave] ballot of the rays that carry dose
     __shared__ int sHist[kMaxSuperpR + 2];
@@ -798,18 +798,26 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
     // dealt in rounds of nCU that alternate direction — a CU that got an expensive walk in one round gets a cheap one in the
     // next — with the direction chosen so that the last, partial round (the cheapest walks) lands on the CUs that received the
     // cheapest walks of the last full round. (Performance only: any placement gives the same result.)
+    // (More walks than can be co-resident — the reference's water cube: 2560 on 256 CUs — are still dealt this way, up to
+    //  kFillSnakeRounds per CU: the first rounds land as described, the rest wherever a slot frees. Measured and dropped there: as many
+    //  blocks as fit the GPU at once, each taking walk after walk from a ticket counter in descending order of cost — the loop costs
+    //  the kernel 23 registers, 5 blocks per CU instead of 7: 0.325 ms against 0.27.)
     const int nTiles = fc.tilesX * fc.tilesY, nB = 2 * nTiles * fc.L;
+    const int tid = threadIdx.y * 32 + threadIdx.x;                  // ray of the tile
     int item = blockIdx.x;
-    if (nB <= 6 * nCU) {
+    if (nB <= kFillSnakeRounds * nCU) {
         const int rr = blockIdx.x / nCU, c = blockIdx.x % nCU, nFull = nB / nCU;
         const bool reversed = rr < nFull && ((nFull - 1 - rr) & 1) == 0;       // the last full round: CU 0 gets its cheapest walk
         item = rr * nCU + (reversed ? nCU - 1 - c : c);
     }
+    const long long dbgT0 = dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
     const int pr = st->fillItems[item / nTiles];
     const int layer = pr >> 1;
     const int role = pr & 1;                                         // block-uniform: 0 sigma walk, 1 dose walk
-    const int tileNo = item % nTiles, tileX = tileNo % fc.tilesX, tileY = tileNo / fc.tilesX;
-    const int tid = threadIdx.y * 32 + threadIdx.x;                  // ray of the tile
+    // (the tile is rotated with the walk's index: when the tile count divides the CU count — 64 tiles on 256 CUs, the reference's water
+    //  cube — block b and b + nCU would otherwise hold the same tile, and the CUs of the cheap edge tiles would get cheap walks in every round:
+    //  measured 1.2 M against 2.6 M block-cycles per CU)
+    const int tileNo = (item % nTiles + (item / nTiles) * 5) % nTiles, tileX = tileNo % fc.tilesX, tileY = tileNo / fc.tilesX;
     const int wave = tid >> 6;
     const int x = tileX * kSuperpTileX + threadIdx.x;
     const int y = tileY * kSuperpTileY + threadIdx.y;
@@ -1053,7 +1061,7 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
         if (NUC && nucIdx >= 0 && pFirst < pAfterLast) nuc.idd[(size_t)layer * fc.nucW * fc.nucH + nucIdx] = nucRes;   // value of the last step (:367-373)
     }
     if (dbg && tid == 0) {
-        long long* q = dbg + 4 * (size_t)blockIdx.x;
+        long long* q = dbg + 4 * (size_t)item;
         q[0] = dbgT0; q[1] = (long long)__builtin_amdgcn_s_memtime();
         q[2] = ((long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32) | (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
         q[3] = ((long long)item << 8) | (long long)(role << 4) | 0;

@@ -10,21 +10,22 @@
 //   pass 1 (along y), transposed:  t[c][y] = sum_r in[r][c] w[|r - (y - 32)|]     A[i = c][k = r]: for a k step the 16 lanes of a quarter
 //            read 16 consecutive columns of ONE ray row; B[k = r][j = y] from the layer's weight table (64 floats of LDS per wave).
 //            D[i = c][j = y]: lane = output row y, registers = 4 columns.
-//   pass 2 (along x):  out[y][x] = sum_c t[c][y] w[|c - (x - 32)|]     A[i = y][k = c] IS pass 1's result where it lies: the sum over k may
-//            run over any four columns per step, so k step s of column block cb takes the columns 16 cb + 4 kq + s — register s of
-//            the lanes' own D. No transposition, no LDS round trip. B[k = c][j = x] from the weight table again. D[i = y][j = x]: stored
-//            as 64-byte rows.
+//   pass 2 (along x):  out[y][x] = sum_c t[c][y] w[|c - (x - 32)|]     A[i = y][k = c] IS pass 1's result where it lies: register s of
+//            the lanes' own D is k step s. Pass 1 loads row i of its A from column 4 (i % 4) + i / 4 of the block (a permutation
+//            within the same 64 bytes), so that D's register s of quarter kq is column 4 s + kq: a k step is four CONSECUTIVE columns,
+//            and the steps outside an output block's reach are skipped. No transposition, no LDS round trip. B[k = c][j = x] from the
+//            weight table again. D[i = y][j = x]: stored as 64-byte rows.
 // The weights (the same pixel integrals as the general kernels: Taylor series for sigma >= 1.4 px, erf differences below) depend on the
 // layer only: a wave looks its B operands up once per layer (12 + 20 registers), not per product. The layers of a slice are added in
 // ascending order into the same accumulators (12 column blocks): reproducible.
 //   k_superpose_uniform3  block = ONE slice, wave = one of its (<= 16) row blocks; the slice's layers staged in two LDS buffers a layer
 //                         ahead, one barrier per layer. Ray grids of up to 128 columns (the reference's water cube: 0.24 ms).
 //   k_superpose_uniform2  wave = (slice, row block, strip of 192 columns), A operands straight from global memory (the input rows are
-//                         re-read by the row blocks within reach, through L1 / L2), no barrier in the loop: any grid (0.335 ms there — a
+//                         re-read by the row blocks within reach, through L1 / L2), no barrier in the loop: any grid (0.32 ms there — a
 //                         wave waits a memory round trip per input column block).
 // History on the reference's water cube (256^3, 20 layers; the general kernel of round 2 took 1.18 ms): vector ALUs with a sliding window
 // 0.71 ms; first matrix version 0.67 ms; round 2's kernel — x pass, barrier, y pass, barrier per 32-row chunk staged in LDS, four waves
-// per block, matrix cores busy 19 % — 0.36 ms; these two 0.335 and 0.24 ms. What is left is mostly matrix work: at the cube's radii
+// per block, matrix cores busy 19 % — 0.36 ms; these two 0.32 and 0.24 ms. What is left is mostly matrix work: at the cube's radii
 // (up to 16) a wave issues ~250 MFMAs per layer, two thirds of them in pass 2 (12 output column blocks against 8 input ones).
 #pragma once
 #include "rtd_kernels.hpp"
@@ -140,12 +141,12 @@ __global__ __launch_bounds__(256, 2) void k_superpose_uniform2(const float* __re
                 const int d = d1 + 4 * s;
                 b1[s] = s < nK ? sw[min(d < 0 ? -d : d, kU2Guard)] : 0.0f;
             }
-            const int d2 = 4 * kq - li - 32;
+            const int d2 = kq - li - 32;
 #pragma unroll
             for (int jj = 0; jj < kU2Reach; ++jj)
 #pragma unroll
                 for (int s2 = 0; s2 < 4; ++s2) {
-                    const int d = d2 + 16 * jj + s2;
+                    const int d = d2 + 16 * jj + 4 * s2;
                     b2[jj][s2] = sw[min(d < 0 ? -d : d, kU2Guard)];
                 }
         }
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void k_superpose_uniform2(const float* __re
             const bool need = cb >= 0 && cb < nCB && 16 * cb + 15 >= x0 - 32 - rho && 16 * cb <= x0 + 16 * kU2XB - 17 + rho;
             if (!need) continue;                                     // (wave-uniform)
             f32x4 tmp = {0.0f, 0.0f, 0.0f, 0.0f};
-            const float* col = in + 16 * cb + li;
+            const float* col = in + 16 * cb + 4 * (li & 3) + (li >> 2);   // row i of A <-> column 4 (i % 4) + i / 4 of the block (see pass 2)
             // pass 1: the first kU2Run k steps (radii up to 14 need no more) requested together, the rest when the radius asks
             {
                 float av[kU2Run];
@@ -189,11 +190,10 @@ __global__ __launch_bounds__(256, 2) void k_superpose_uniform2(const float* __re
                 if (q < 0 || q >= kU2XB) continue;
                 const int xq = x0 + 16 * q;                          // first padded-BEV column of the output block
                 // ray columns of the input block [16 cb, 16 cb + 15] against the block's reach [xq - 32 - rho, xq - 17 + rho]
-                if (16 * cb + 15 >= xq - 32 - rho && 16 * cb <= xq - 17 + rho) {      // (wave-uniform)
 #pragma unroll
-                    for (int s2 = 0; s2 < 4; ++s2)
+                for (int s2 = 0; s2 < 4; ++s2)                       // k step s2 = the block's columns 4 s2 .. 4 s2 + 3: only those within the reach
+                    if (16 * cb + 4 * s2 + 3 >= xq - 32 - rho && 16 * cb + 4 * s2 <= xq - 17 + rho)      // (wave-uniform)
                         acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(tmp[s2], b2[jj][s2], acc[q], 0, 0, 0);
-                }
             }
         }
     }
@@ -334,12 +334,12 @@ __global__ __launch_bounds__(kMaxThreads) void k_superpose_uniform3(const float*
                     const int d = d1 + 4 * s;
                     b1[s] = s < nK ? sw[min(d < 0 ? -d : d, kU2Guard)] : 0.0f;
                 }
-                const int d2 = 4 * kq - li - 32;
+                const int d2 = kq - li - 32;
 #pragma unroll
                 for (int jj = 0; jj < kU2Reach; ++jj)
 #pragma unroll
                     for (int s2 = 0; s2 < 4; ++s2) {
-                        const int d = d2 + 16 * jj + s2;
+                        const int d = d2 + 16 * jj + 4 * s2;
                         b2[jj][s2] = sw[min(d < 0 ? -d : d, kU2Guard)];
                     }
             }
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(kMaxThreads) void k_superpose_uniform3(const float*
                 const bool need = cb >= 0 && cb < nCB && 16 * cb + 15 >= -32 - rho && 16 * cb <= 16 * kU2XB - 17 + rho;
                 if (!need) continue;                                 // (wave-uniform)
                 f32x4 tmp = {0.0f, 0.0f, 0.0f, 0.0f};
-                const float* col = in + 16 * cb + li;
+                const float* col = in + 16 * cb + 4 * (li & 3) + (li >> 2);   // row i of A <-> column 4 (i % 4) + i / 4 of the block (see pass 2)
                 {
                     float av[kU2Run];
 #pragma unroll
@@ -380,11 +380,10 @@ __global__ __launch_bounds__(kMaxThreads) void k_superpose_uniform3(const float*
                     const int q = j - jj;                            // (static)
                     if (q < 0 || q >= kU2XB) continue;
                     const int xq = 16 * q;
-                    if (16 * cb + 15 >= xq - 32 - rho && 16 * cb <= xq - 17 + rho) {      // (wave-uniform)
 #pragma unroll
-                        for (int s2 = 0; s2 < 4; ++s2)
+                    for (int s2 = 0; s2 < 4; ++s2)                   // k step s2 = the block's columns 4 s2 .. 4 s2 + 3: only those within the reach
+                        if (16 * cb + 4 * s2 + 3 >= xq - 32 - rho && 16 * cb + 4 * s2 <= xq - 17 + rho)      // (wave-uniform)
                             acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(tmp[s2], b2[jj][s2], acc[q], 0, 0, 0);
-                    }
                 }
             }
         }
