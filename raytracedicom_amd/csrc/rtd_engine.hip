@@ -102,6 +102,7 @@ struct rtd_field_impl {
     int* dNodeCount = nullptr;   // [output tile][step][32] arrival counters of the superposition's reduction tree (all zero between launches)
     int *dFirstInside = nullptr, *dFirstOutside = nullptr, *dFirstPassive = nullptr, *dWeplMin = nullptr;
     float* dBlockWeplMin = nullptr;   // [R/64][S] per scan block and step: smallest WEPL of the block's 64 rays
+    float* dSegPos = nullptr;         // [S / kTraceSeg + 1][3][R] sample positions at the segment boundaries of k_trace_sample (walked once, at creation)
     unsigned char* dTileRad = nullptr;
     size_t tileRadWords = 0;
     LayerPlan* dLayers = nullptr;
@@ -124,6 +125,7 @@ struct rtd_field_impl {
     long long* dFillDbg = nullptr; size_t fillDbgN = 0;   // RTD_FILL_DEBUG: per-block clock stamps of k_fill (diagnostics)
     long long* dSweepDbg = nullptr; size_t sweepDbgN = 0; // RTD_SWEEP_DEBUG: per-block clock stamps of k_superpose_sweep (diagnostics)
     long long* dSweepBigDbg = nullptr; size_t sweepBigDbgN = 0; // ... and of k_superpose_sweep_big
+    long long* dScanDbg = nullptr; size_t scanDbgN = 0;         // RTD_SCAN_DEBUG: ... of k_trace_scan
     FieldState* dState = nullptr;
     FieldState* hState = nullptr;      // pinned host mirror of *dState (written by k_ks_plan), and its device-side address
     FieldState* dHostState = nullptr;
@@ -487,8 +489,8 @@ int rtd_field_destroy(rtd_handle hh, rtd_field ff) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = { f->dSpotWeights, f->dConvInterm, f->dRayWeights, f->dDensity, f->dWepl, f->dRrl, f->dIdd, f->dRSigma, f->dBev, f->dBevPart, f->dNodeCount, f->dSwSlots, f->dSwCount, f->dSwSlotsBig, f->dSwCountBig,
-                     f->dFirstInside, f->dFirstOutside, f->dFirstPassive, f->dWeplMin, f->dBlockWeplMin, f->dTileRad,
-                     f->dLayers, f->dState, f->dStepTab, f->dActive, f->dSigMin, f->dSigMax, f->dFillDbg, f->dSweepDbg, f->dSweepBigDbg,
+                     f->dFirstInside, f->dFirstOutside, f->dFirstPassive, f->dWeplMin, f->dBlockWeplMin, f->dSegPos, f->dTileRad,
+                     f->dLayers, f->dState, f->dStepTab, f->dActive, f->dSigMin, f->dSigMax, f->dFillDbg, f->dSweepDbg, f->dSweepBigDbg, f->dScanDbg,
                      f->dNucSpotIdx, f->dNucRayWeights, f->dNucIdd, f->dNucRs, f->dNucBev, f->dNucEffT, f->dStateNuc };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (f->hState) (void)hipHostFree(f->hState);
@@ -650,7 +652,7 @@ static int createField(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dim
         f->dSpotWeights = husk->dSpotWeights; f->dConvInterm = husk->dConvInterm; f->dRayWeights = husk->dRayWeights;
         f->dDensity = husk->dDensity; f->dWepl = husk->dWepl; f->dRrl = husk->dRrl; f->dIdd = husk->dIdd; f->dRSigma = husk->dRSigma;
         f->dBev = husk->dBev; f->dBevPart = husk->dBevPart; f->dNodeCount = husk->dNodeCount; f->dSwSlots = husk->dSwSlots; f->dSwCount = husk->dSwCount; f->dSwSlotsBig = husk->dSwSlotsBig; f->dSwCountBig = husk->dSwCountBig; f->dFirstInside = husk->dFirstInside; f->dFirstOutside = husk->dFirstOutside;
-        f->dFirstPassive = husk->dFirstPassive; f->dWeplMin = husk->dWeplMin; f->dBlockWeplMin = husk->dBlockWeplMin; f->dTileRad = husk->dTileRad; f->dLayers = husk->dLayers;
+        f->dFirstPassive = husk->dFirstPassive; f->dWeplMin = husk->dWeplMin; f->dBlockWeplMin = husk->dBlockWeplMin; f->dSegPos = husk->dSegPos; f->dTileRad = husk->dTileRad; f->dLayers = husk->dLayers;
         f->dState = husk->dState; f->dStepTab = husk->dStepTab; f->dActive = husk->dActive; f->dSigMin = husk->dSigMin; f->dSigMax = husk->dSigMax; f->hState = husk->hState; f->dHostState = husk->dHostState;
         for (int i = 0; i < 9; ++i) f->ev[i] = husk->ev[i];
         delete husk;
@@ -666,12 +668,17 @@ static int createField(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dim
         A(&f->dSwSlots, (size_t)S * f->swPX * f->swPY * f->swGroups * kSwSlot); A(&f->dSwCount, (size_t)S);
         A(&f->dSwSlotsBig, (size_t)S * f->swPX * f->swPY * f->bgGroups * kBgSlot); A(&f->dSwCountBig, (size_t)S);
     }
-    A(&f->dFirstInside, R); A(&f->dFirstOutside, R); A(&f->dFirstPassive, R * L); A(&f->dWeplMin, (size_t)S); A(&f->dBlockWeplMin, (R / 64) * (size_t)S);
+    A(&f->dFirstInside, R); A(&f->dFirstOutside, R); A(&f->dFirstPassive, R * L); A(&f->dWeplMin, (size_t)S); A(&f->dBlockWeplMin, (R / 64) * (size_t)S); A(&f->dSegPos, ((size_t)S / kTraceSeg + 1) * 3 * R);
     A(&f->dTileRad, f->tileRadWords * 4); A(&f->dLayers, (size_t)L); A(&f->dState, (size_t)1); A(&f->dStepTab, (size_t)2 * S); A(&f->dActive, (size_t)4 * L * S); A(&f->dSigMin, (size_t)L * S); A(&f->dSigMax, (size_t)L * S);
     if (st != RTD_OK) { rtd_field_destroy(hh, reinterpret_cast<rtd_field>(f)); return st; }
     hipError_t e = hipMemcpy(f->dSpotWeights, b->spot_weights, nSpot * sizeof(float), hipMemcpyHostToDevice);   // :851
     if (e == hipSuccess) e = hipMemcpy(f->dLayers, f->hLayers.data(), (size_t)L * sizeof(LayerPlan), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(f->dState, 0, sizeof(FieldState));
+    if (e == hipSuccess) {   // the sample positions at the segment boundaries of k_trace_sample: geometry only, walked once
+        k_trace_segpos<<<(unsigned)((R + 255) / 256), 256, 0, h->stream>>>(f->tracer, fc.W, (int)R, f->dSegPos);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    }
     if (e == hipSuccess && fresh) e = hipHostMalloc((void**)&f->hState, sizeof(FieldState), hipHostMallocMapped);
     if (e == hipSuccess && fresh) e = hipHostGetDevicePointer((void**)&f->dHostState, f->hState, 0);
     if (e == hipSuccess) std::memset(f->hState, 0, sizeof(FieldState));
@@ -821,18 +828,23 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
                 (const float*)h->dCt, (int)h->ctDims[0], (int)h->ctDims[1], (int)h->ctDims[2], h->lut, f->tracer, fc.W, fc.H, f->dDensity, f->dWepl, f->dIdd,
                 f->dRrl, h->rrlScale, f->dState);
     } else {
-        launchK(k_trace_sample, dim3((unsigned)(f->R / 256), (fc.S + kTraceSeg - 1) / kTraceSeg), dim3(256), lutLds, s, f->ev[0], nullptr,
+        launchK(k_trace_sample, dim3((unsigned)(f->R / 256), (fc.S + kTraceSeg * kTraceSegsPerBlock - 1) / (kTraceSeg * kTraceSegsPerBlock)), dim3(256, kTraceSegsPerBlock), lutLds, s, f->ev[0], nullptr,
                 (const float*)h->dCt, (int)h->ctDims[0], (int)h->ctDims[1], (int)h->ctDims[2], h->lut, f->tracer, fc.W, fc.H, f->dDensity, f->dWepl, f->dIdd,
-                f->dRrl, h->rrlScale, f->dState);
+                f->dRrl, h->rrlScale, f->dState, (const float*)f->dSegPos);
     }
     constexpr size_t scanLds = 2 * kScanChunk * 64 * sizeof(float);   // 128 KiB: above the 64 KiB default cap of dynamic LDS
     if (!h->scanLdsSet) {
         RTD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_trace_scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scanLds));
         h->scanLdsSet = true;
     }
+    if (!f->dScanDbg && std::getenv("RTD_SCAN_DEBUG")) {
+        f->scanDbgN = (size_t)8 * (f->R / 64);
+        RTD_HIP(h, hipMalloc((void**)&f->dScanDbg, f->scanDbgN * sizeof(long long)));
+        RTD_HIP(h, hipMemset(f->dScanDbg, 0, f->scanDbgN * sizeof(long long)));
+    }
     const ResetJob resetJob{f->dLayers, fc.L, reinterpret_cast<unsigned int*>(f->dTileRad), f->tileRadWords, f->dActive, (size_t)4 * fc.L * fc.S,
                             f->dNucIdd, f->dNucRs, fc.nuclearCorr ? (size_t)fc.nucW * fc.nucH * fc.L : (size_t)0,
-                            f->dSigMin, f->dSigMax, (size_t)fc.L * fc.S};
+                            f->dSigMin, f->dSigMax, (size_t)fc.L * fc.S, f->dScanDbg};
     launchK(k_trace_scan, dim3((unsigned)(f->R / 64)), dim3(64, kScanWaves), scanLds, s, nullptr, ev(1), (const float*)f->dIdd, f->dWepl, fc.W, fc.H,
             (unsigned)fc.S, f->dFirstInside, f->dFirstOutside, f->dState, f->dBlockWeplMin, resetJob);
     if (fc.spotNy <= kPlanConvMaxRows && std::getenv("RTD_SEPARATE_PLAN") == nullptr) {
@@ -1252,6 +1264,7 @@ int rtd_field_fetch(rtd_handle hh, rtd_field ff, const char* name, void* host_ou
     else if (nm == "fill_debug" && f->dFillDbg) { src = f->dFillDbg; n = f->fillDbgN * sizeof(long long); }
     else if (nm == "sweep_debug" && f->dSweepDbg) { src = f->dSweepDbg; n = f->sweepDbgN * sizeof(long long); }
     else if (nm == "sweep_big_debug" && f->dSweepBigDbg) { src = f->dSweepBigDbg; n = f->sweepBigDbgN * sizeof(long long); }
+    else if (nm == "scan_debug" && f->dScanDbg) { src = f->dScanDbg; n = f->scanDbgN * sizeof(long long); }
     else if (nm == "eff_radius" || nm == "layer_plan") {
         std::vector<LayerPlan> lp(L);
         RTD_HIP(h, hipMemcpy(lp.data(), f->dLayers, L * sizeof(LayerPlan), hipMemcpyDeviceToHost));

@@ -216,6 +216,7 @@ struct ResetJob {
     int* active; size_t nActive;
     float* nucIdd; float* nucRs; size_t nNuc;      // NUCLEAR_CORR: (0, inf) = the reference's fills at kernel_wrapper.cu:862-863
     unsigned int* sigMin; unsigned int* sigMax; size_t nSig;   // per (layer, step): bits of the smallest / largest tile-uniform sigma^2
+    long long* scanDbg;             // diagnostic build only (RTD_SCAN_DEBUG): clock stamps of k_trace_scan's blocks, 8 per block
 };
 __device__ inline void resetFieldArrays(const ResetJob& j, size_t t, size_t nT) {
     for (size_t l = t; l < (size_t)j.L; l += nT) {
@@ -239,43 +240,71 @@ __device__ inline void resetFieldArrays(const ResetJob& j, size_t t, size_t nT) 
 //                   logic over the stored terms, fused with the int reductions that follow the tracer in the
 //                   reference (sliceMin/MaxVar<int>, kernel_wrapper.cu:781-787).
 // Rays are numbered row-major; lanes hold consecutive rays, so all stores are coalesced and step-major.
-constexpr int kTraceSeg = 8;
+constexpr int kTraceSeg = 9, kTraceSegsPerBlock = 2;   // a block = 256 rays x 2 segments (8 waves share one copy of the LUT rows in LDS)
 
-__global__ __launch_bounds__(256) void k_trace_sample(const float* __restrict__ ct, int nx, int ny, int nz, LutView lut,
+// The sample positions are the serial `pos += step` sequence of the reference walk (kernel_wrapper.cu:183) — not start + k * step in
+// floating point — so a thread that starts at step k0 has to know the k0-th term. They depend on the field's geometry only: the
+// positions at the segment boundaries are walked once, when the field is created (one thread per ray), and k_trace_sample starts
+// from them. (Until round 3 every thread replayed the additions up to its k0: 250 steps on average, ~45 % of the kernel's
+// vector instructions.) segPos[(segment * 3 + component) * R + ray].
+__global__ __launch_bounds__(256) void k_trace_segpos(TracerParams tp, int W, int R, float* __restrict__ segPos) {
+    const int ray = blockIdx.x * 256 + threadIdx.x;
+    if (ray >= R) return;
+    const int x = ray % W, y = ray / W;
+    Vec3 pos = tp.getStart(x, y);
+    const Vec3 step = tp.getInc(x, y);
+    for (unsigned int k = 0, seg = 0; k <= tp.steps; ++k) {
+        if (k % kTraceSeg == 0) {
+            float* q = segPos + (size_t)seg * 3 * R + ray;
+            q[0] = pos.x; q[(size_t)R] = pos.y; q[2 * (size_t)R] = pos.z;
+            ++seg;
+        }
+        pos = pos + step;
+    }
+}
+
+__global__ __launch_bounds__(256 * kTraceSegsPerBlock) void k_trace_sample(const float* __restrict__ ct, int nx, int ny, int nz, LutView lut,
                                                        TracerParams tp, int W, int H, float* __restrict__ bevDensity,
                                                        float* __restrict__ spTerm, float* __restrict__ huBuf,
-                                                       float* __restrict__ bevRrl, float rRlScale, FieldState* st) {
+                                                       float* __restrict__ bevRrl, float rRlScale, FieldState* st,
+                                                       const float* __restrict__ segPos) {
     extern __shared__ float sLut[];
     float* sDensity = sLut;
     float* sSp = sLut + lut.nDensity;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.y * 256 + threadIdx.x;
+    constexpr int nT = 256 * kTraceSegsPerBlock;
     if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) resetFieldScalars(st);     // (the scan, next launch, accumulates into them)
-    const int ray = blockIdx.x * 256 + tid;
+    const int ray = blockIdx.x * 256 + threadIdx.x;
     const int x = ray % W, y = ray / W;
     const size_t memStep = (size_t)W * H;
-    const unsigned int k0 = blockIdx.y * kTraceSeg;
+    const unsigned int k0 = min((blockIdx.y * kTraceSegsPerBlock + threadIdx.y) * kTraceSeg, tp.steps);
     const unsigned int k1 = min(k0 + kTraceSeg, tp.steps);
 
     // the LUT rows travel to LDS while the start position of the segment is being accumulated
-    constexpr int kLutRegs = 16;                                     // covers 2 x 2048 entries in registers; longer tables loop
+    constexpr int kLutRegs = 12;                                     // covers 2 x 3072 entries in registers; longer tables loop
     float rl[kLutRegs];
     const int nLut = lut.nDensity + lut.nSp;
 #pragma unroll
     for (int j = 0; j < kLutRegs; ++j) {
-        const int i = tid + 256 * j;
+        const int i = tid + nT * j;
         rl[j] = i < lut.nDensity ? lut.density[i] : (i < nLut ? lut.sp[i - lut.nDensity] : 0.0f);
     }
-    Vec3 pos = tp.getStart(x, y);     // texel-centre +0.5 of kernel_wrapper.cu:142 is implicit in the sampler
+    // position at the segment's first step (k_trace_segpos: the serial walk's own value; texel-centre +0.5 of kernel_wrapper.cu:142
+    // is implicit in the sampler)
+    const unsigned int seg = blockIdx.y * kTraceSegsPerBlock + threadIdx.y;
+    Vec3 pos = v3(0.0f, 0.0f, 0.0f);
+    if (k0 < k1) {
+        const float* q = segPos + (size_t)seg * 3 * memStep + ray;
+        pos = v3(q[0], q[memStep], q[2 * memStep]);
+    }
     const Vec3 step = tp.getInc(x, y);
     const float stepLen = tp.stepLen(x, y);
-    for (unsigned int i = 0; i < k0; ++i) pos = pos + step;          // same float sequence as the serial walk (:183)
 #pragma unroll
-    for (int j = 0; j < kLutRegs; ++j) { const int i = tid + 256 * j; if (i < nLut) sLut[i] = rl[j]; }
-    for (int i = tid + 256 * kLutRegs; i < nLut; i += 256) sLut[i] = i < lut.nDensity ? lut.density[i] : lut.sp[i - lut.nDensity];
+    for (int j = 0; j < kLutRegs; ++j) { const int i = tid + nT * j; if (i < nLut) sLut[i] = rl[j]; }
+    for (int i = tid + nT * kLutRegs; i < nLut; i += nT) sLut[i] = i < lut.nDensity ? lut.density[i] : lut.sp[i - lut.nDensity];
     __syncthreads();
     size_t idx = (size_t)k0 * memStep + ray;
-    for (unsigned int i = k0; i < k1; ++i) {
-        const float huPlus1000 = sample3dBorder(ct, nx, ny, nz, pos.x, pos.y, pos.z);
+    auto emit = [&](float huPlus1000) {
         huBuf[idx] = huPlus1000;
         const float density = sample1dClamp(sDensity, lut.nDensity, huPlus1000 * tp.densityScale);
         bevDensity[idx] = density;
@@ -284,6 +313,12 @@ __global__ __launch_bounds__(256) void k_trace_sample(const float* __restrict__ 
         // not depend on the energy layer, so it is evaluated here once per (ray, step) instead of once per layer in k_fill
         bevRrl[idx] = density * sample1dClamp(lut.rrl, lut.nRrl, density * rRlScale);
         idx += memStep;
+    };
+    // (Measured and dropped: the corner loads of three steps requested together — 74 registers, six waves per SIMD instead of eight:
+    //  the stage 78 us against 66. What hides the round trips here is the number of resident waves.)
+    unsigned int i = k0;
+    for (; i < k1; ++i) {
+        emit(sample3dBorder(ct, nx, ny, nz, pos.x, pos.y, pos.z));
         pos = pos + step;
     }
 }
@@ -296,6 +331,9 @@ __global__ __launch_bounds__(256) void k_trace_sample(const float* __restrict__ 
 // Oblique beams: a mapping with 8 rays x 8 steps per wave (compact in the rotated plane) measured 0.126 ms at every angle,
 // never better than the better of the two lane directions (plain: 0.076 ms at 0 deg, 0.130 at 30, 0.166 at 45; this one: 0.135
 // at 30, 0.128 at 45, 0.100 at 90), so the host just picks between those two.
+// (The lanes of this kernel walk the whole ray to get from one of their steps to the next; starting from k_trace_segpos's table
+//  instead — one more memory round trip in front of the samples — measured no gain here: 0.086 against 0.091 ms at 90 deg, 0.131
+//  against 0.120 at 45.)
 constexpr int kTrRays = 16, kTrSteps = 512, kTrPitch = kTrSteps + 4;
 __global__ __launch_bounds__(64 * kTrRays) void k_trace_sample_t(const float* __restrict__ ct, int nx, int ny, int nz, LutView lut,
                                                                   TracerParams tp, int W, int H, float* __restrict__ bevDensity,
@@ -373,6 +411,10 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_trace_scan(const float* __r
     const int lane = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
     const int ray = blockIdx.x * 64 + lane;
     const size_t memStep = (size_t)W * H;
+    long long* dbg = reset.scanDbg ? reset.scanDbg + 8 * (size_t)blockIdx.x : nullptr;
+    int dbgN = 0;
+    auto stamp = [&]() { if (dbg && wv == 0 && lane == 0 && dbgN < 8) dbg[dbgN++] = (long long)__builtin_amdgcn_s_memtime(); };
+    stamp();
     // the waves without a serial chain reset the per-layer records, the tile-radius bytes and the dose rectangles (K0)
     if (wv >= 3) resetFieldArrays(reset, ((size_t)blockIdx.x * (kScanWaves - 3) + (wv - 3)) * 64 + lane, (size_t)gridDim.x * (kScanWaves - 3) * 64);
     auto sHu = [&](int, int i) -> float& { return sScan[i * 64 + lane]; };
@@ -395,6 +437,7 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_trace_scan(const float* __r
     fetch(0);
     stage(0);
     __syncthreads();
+    stamp();
     int buf = 0;
     for (unsigned int c0 = 0; c0 < steps; c0 += kScanChunk, buf ^= 1) {
         if (c0 + kScanChunk < steps) fetch(c0 + kScanChunk);         // in flight during the walks below
@@ -409,14 +452,23 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_trace_scan(const float* __r
                 for (int j = 0; j < kU; ++j) { cumulSp += v[j]; sSp(buf, j0 + j) = cumulSp; }
             }
         } else if (wv == 1) {
-            for (int j0 = 0; j0 < kScanChunk; j0 += kU) {
+            // "the last step at which the running sum is below 150" as a running maximum of the steps where it is: the sums are one
+            // chain of dependent additions, the maximum another, and neither waits for a compare-and-branch per step (the first form
+            // of this loop: 63 cycles per step, 56 % of the kernel — clock stamps, tools/scan_dbg.py)
+            const int nJ = (int)min((unsigned int)kScanChunk, steps - c0);          // steps of this chunk (the rest was staged as zeros)
+            for (int j0 = 0; j0 < nJ; j0 += kU) {
                 float v[kU];
 #pragma unroll
                 for (int j = 0; j < kU; ++j) v[j] = sHu(buf, j0 + j);
 #pragma unroll
-                for (int j = 0; j < kU; ++j) {
-                    cumulHuPlus1000 += v[j];
-                    if (cumulHuPlus1000 < 150.0f && c0 + j0 + j < steps) beforeFirstInside = (int)(c0 + j0 + j);
+                for (int j = 0; j < kU; ++j) { cumulHuPlus1000 += v[j]; v[j] = cumulHuPlus1000; }
+                const int i0 = (int)c0 + j0;
+                if (j0 + kU <= nJ) {                                 // (wave-uniform)
+#pragma unroll
+                    for (int j = 0; j < kU; ++j) beforeFirstInside = max(beforeFirstInside, v[j] < 150.0f ? i0 + j : -1);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < kU; ++j) beforeFirstInside = max(beforeFirstInside, (v[j] < 150.0f && j0 + j < nJ) ? i0 + j : -1);
                 }
             }
         } else if (wv == 2) {
@@ -424,16 +476,21 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_trace_scan(const float* __r
                 float v[kU];
 #pragma unroll
                 for (int j = 0; j < kU; ++j) v[j] = sHu(buf, j0 + j);
+                const int i0 = (int)c0 + j0;                         // (zeros beyond the last step never pass the test)
 #pragma unroll
-                for (int j = 0; j < kU; ++j) if (v[j] > 150.0f) lastInside = (int)(c0 + j0 + j);
+                for (int j = 0; j < kU; ++j) lastInside = max(lastInside, v[j] > 150.0f ? i0 + j : -1);
             }
         }
         ldsBarrier();                                                // chunk walked
+        stamp();
+        float wOut[kScanPerWave];                                    // (all LDS reads first: one round trip, not one per step)
+#pragma unroll
+        for (int j = 0; j < kScanPerWave; ++j) wOut[j] = sSp(buf, wv * kScanPerWave + j);
 #pragma unroll
         for (int j = 0; j < kScanPerWave; ++j) {                     // all waves store the chunk's WEPL
             const unsigned int i = c0 + wv * kScanPerWave + j;
             if (i < steps) {
-                const float wepl = sSp(buf, wv * kScanPerWave + j);
+                const float wepl = wOut[j];
                 bevCumulSp[ray + (size_t)i * memStep] = wepl;
                 // sliceMinVar<float> (kernel_wrapper.cuh:215-244, launch kernel_wrapper.cu:788), first level: this block's 64 rays;
                 // k_plan takes the minimum over the blocks (one value per block and step instead of a pass over all of WEPL)
@@ -441,10 +498,12 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_trace_scan(const float* __r
                 if (lane == 0) blockWeplMin[(size_t)blockIdx.x * steps + i] = m;
             }
         }
+        stamp();
         if (c0 + kScanChunk < steps) {
             ldsBarrier();                                            // chunk stored: the buffer takes the next one
             stage(buf);
             ldsBarrier();
+            stamp();
         }
     }
     if (wv == 1) {

@@ -1,0 +1,26 @@
+"""Clock stamps of k_trace_scan's blocks on the bench field (RTD_SCAN_DEBUG=1)."""
+import os, sys
+os.environ["RTD_SCAN_DEBUG"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+torch.cuda.init()
+from raytracedicom_amd import engine, luts, scenarios
+es = luts.synth_luts()
+ct, _ = scenarios.hetero_phantom(512)
+scn = scenarios.hetero_ct(es, n=512, angles=[0.0], ct=ct)
+eng = engine.Engine(0)
+eng.set_luts(es); eng.set_ct(scn.ct)
+d = eng.device_alloc(4 * scn.n_voxels); eng.device_zero(d, 4 * scn.n_voxels)
+f = eng.create_field(scn.beams[0], scn.dims)
+for i in range(3):
+    f.compute(d); t, info = f.finish()
+q = f.fetch("scan_debug").reshape(-1, 8).astype(np.float64)
+t0 = q[:, 0].min()
+names = ["start", "chunk 0 staged", "chunk 0 walked", "chunk 0 stored", "chunk 1 staged", "chunk 1 walked", "chunk 1 stored"]
+print("blocks", q.shape[0])
+for i, nm in enumerate(names):
+    print("%-16s mean %9.0f  min %9.0f max %9.0f (ticks since the first block's start)" % (nm, (q[:, i] - t0).mean(), (q[:, i] - t0).min(), (q[:, i] - t0).max()))
+for i in range(1, 7):
+    print("  phase -> %-16s mean %8.0f max %8.0f" % (names[i], (q[:, i] - q[:, i - 1]).mean(), (q[:, i] - q[:, i - 1]).max()))
+f.destroy(); eng.close()
