@@ -289,7 +289,9 @@ __global__ __launch_bounds__(64 * kSwWaves, 2) void k_superpose_sweep_big(const 
         // ---- flush, in ascending source-row order — per COLUMN BLOCK: eight tickets, so that the rows' flushes overlap like a pipeline
         //      (row ri adds its block t while row ri + 1 adds its block t - 1; an element still receives its addends in row order).
         //      With one ticket for the whole row the 64 flushes of a block were its critical path (measured: 3.4 k cycles each,
-        //      220 k of a block's 245 k, whatever the number of sources). ----
+        //      220 k of a block's 245 k, whatever the number of sources). (Requesting block t + 1's tile values before block t is written —
+        //      one LDS round trip per step instead of two — measured slower, 199 k against 134 k: a row then holds block t until it has
+        //      block t + 1's ticket, and the rows move in a convoy.) ----
         const long long df0 = dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
 #pragma unroll
         for (int tg = 0; tg < kBgNCB / kBgTk; ++tg) {
