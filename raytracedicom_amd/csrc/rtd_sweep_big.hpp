@@ -302,28 +302,33 @@ __global__ __launch_bounds__(64 * kSwWaves, 2) void k_superpose_sweep_big(const 
                 float* outP = sOut + (ri + kBgR + 4 * kq) * kBgPitch + 16 * kBgTk * tg + li;
                 float* outM = sOut + (ri + kBgR - 4 * kq - 3) * kBgPitch + 16 * kBgTk * tg + li;
                 const bool on0 = 4 * kq <= rhoFlush, on1 = 16 + 4 * kq <= rhoFlush;
-                float oP0[kBgTk][4], oM0[kBgTk][4], oP1[kBgTk][4], oM1[kBgTk][4];
+                // (four predicated regions per step — the reads of the two row tiles, then their writes: with the predicate inside the
+                //  per-register loops the compiler made a branch around every pair of accesses)
+                static_assert(kBgTk == 1, "one column block per ticket");
+                const int t = tg;
+                float oP0[4], oM0[4], oP1[4], oM1[4];
+                if (on0) {
 #pragma unroll
-                for (int u = 0; u < kBgTk; ++u)
+                    for (int r = 0; r < 4; ++r) { oP0[r] = outP[r * kBgPitch]; oM0[r] = outM[(3 - r) * kBgPitch]; }
+                }
+                if (on1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { oP1[r] = outP[(16 + r) * kBgPitch]; oM1[r] = outM[(3 - r - 16) * kBgPitch]; }
+                }
+                if (on0) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        if (on0) { oP0[u][r] = outP[r * kBgPitch + 16 * u]; oM0[u][r] = outM[(3 - r) * kBgPitch + 16 * u]; }
-                        if (on1) { oP1[u][r] = outP[(16 + r) * kBgPitch + 16 * u]; oM1[u][r] = outM[(3 - r - 16) * kBgPitch + 16 * u]; }
+                        outP[r * kBgPitch] = oP0[r] + acc0[t][r];
+                        if (r > 0 || kq > 0) outM[(3 - r) * kBgPitch] = oM0[r] + acc0[t][r];
                     }
-#pragma unroll
-                for (int u = 0; u < kBgTk; ++u)
+                }
+                if (on1) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int t = kBgTk * tg + u;
-                        if (on0) {
-                            outP[r * kBgPitch + 16 * u] = oP0[u][r] + acc0[t][r];
-                            if (r > 0 || kq > 0) outM[(3 - r) * kBgPitch + 16 * u] = oM0[u][r] + acc0[t][r];
-                        }
-                        if (on1) {
-                            outP[(16 + r) * kBgPitch + 16 * u] = oP1[u][r] + acc1[t][r];
-                            outM[(3 - r - 16) * kBgPitch + 16 * u] = oM1[u][r] + acc1[t][r];
-                        }
+                        outP[(16 + r) * kBgPitch] = oP1[r] + acc1[t][r];
+                        outM[(3 - r - 16) * kBgPitch] = oM1[r] + acc1[t][r];
                     }
+                }
                 if (rhoFlush == kBgR) {
 #pragma unroll
                     for (int u = 0; u < kBgTk; ++u) {
