@@ -52,6 +52,7 @@ constexpr int kSwSlot = kSwOutRows * kSwOut;             // floats of a partial 
 constexpr int kSwMaxLay = 64;                        // layers per group (one lane each when the list is made)
 constexpr int kSwMaxGroups = 16;
 constexpr int kSwTileRows = kSwPatchRows / 8 + 1, kSwTileCols = 3;      // 32 x 8 classification tiles a 64 x 64 patch can touch
+constexpr int kSwTk = 3;                             // column blocks per flush ticket (two tickets: 0.309 ms; three tickets of two blocks 0.315, one ticket 0.311)
 constexpr int kSwNDelta = 12;                        // pair offsets delta = -28, -24, ..., 16
 
 // smallest radius at which quad offset delta = (first output column of the block) - (first source of the quad) pairs them:
@@ -228,7 +229,8 @@ __global__ __launch_bounds__(64 * kSwWaves, 4) void k_superpose_sweep(const floa
     __shared__ signed char sEff[kSwMaxLay * kSwTileRows * kSwTileCols];   // [layer slot][9][3] batch radius of the tile (-1: none)
     __shared__ int sRows[kSwMaxLay];                                 // [layer slot]: first | last << 8 patch row that carries dose
     __shared__ int sLay[kSwMaxLay];                                  // [layer slot]: layer
-    __shared__ int sMisc[4];                                         // number of layer slots, flush ticket, "last block of the step"
+    __shared__ int sMisc[4];                                         // number of layer slots, -, "last block of the step"
+    __shared__ int sTicket[kSwNCB / kSwTk];                          // flush tickets: the source row whose turn it is, per group of column blocks
     float* sOut = sw;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     // ---- decode (block-uniform); the deepest steps first (measured: ascending order 0.342 ms against 0.313 ms) ----
@@ -271,7 +273,8 @@ __global__ __launch_bounds__(64 * kSwWaves, 4) void k_superpose_sweep(const floa
             if (hi < lo) { lo = 255; hi = 0; }
             sRows[j] = lo | (hi << 8);
         }
-        if (lane == 0) { sMisc[0] = __popcll(mask); sMisc[1] = 0; }
+        if (lane == 0) sMisc[0] = __popcll(mask);
+        if (lane < kSwNCB / kSwTk) sTicket[lane] = 0;
     }
     for (int i = tid; i < kSwOutRows * kSwPitch; i += 64 * kSwWaves) sOut[i] = 0.0f;
     float* tab = sw + kSwLdsTab + wv * kSwWaveLds;
@@ -379,44 +382,44 @@ __global__ __launch_bounds__(64 * kSwWaves, 4) void k_superpose_sweep(const floa
         }
         // ---- flush T into the patch's output tile, in ascending source-row order (every element: a fixed order of additions) ----
         const long long dw0 = dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
-        while (__hip_atomic_load(&sMisc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != ri) {}
+        // (a ticket per group of kSwTk column blocks: row ri + 1 adds its first group while row ri adds its second)
+        while (__hip_atomic_load(&sTicket[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != ri) {}
         const long long dw1 = dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
         __builtin_amdgcn_s_setprio(3);                               // the flush is the block's serial chain: its instructions go first
-        if (rhoFlush >= 0) {
-            // T[|dy| = 4 kq + r][column 16 t + li] -> rows (ri + 16) +- |dy| of the tile; the minus side skips dy = 0. Plain
-            // read-modify-write: the ticket makes this wave the only writer.
-            float* outP = sOut + (ri + kSwMaxR + 4 * kq) * kSwPitch + li;
-            float* outM = sOut + (ri + kSwMaxR - 4 * kq - 3) * kSwPitch + li;
-            if (4 * kq <= rhoFlush) {
+        // T[|dy| = 4 kq + r][column 16 t + li] -> rows (ri + 16) +- |dy| of the tile; the minus side skips dy = 0. Plain
+        // read-modify-write: the tickets make this wave the only writer of a group.
+        float* outP = sOut + (ri + kSwMaxR + 4 * kq) * kSwPitch + li;
+        float* outM = sOut + (ri + kSwMaxR - 4 * kq - 3) * kSwPitch + li;
 #pragma unroll
-                for (int t0 = 0; t0 < kSwNCB; t0 += 3) {             // three column blocks at a time: 24 reads in flight, then 24 writes
-                    float oP[3][4], oM[3][4];
+        for (int t0 = 0; t0 < kSwNCB; t0 += kSwTk) {                 // kSwTk column blocks at a time: their reads in flight together, then their writes
+            if (t0 > 0) while (__hip_atomic_load(&sTicket[t0 / kSwTk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != ri) {}
+            if (rhoFlush >= 0 && 4 * kq <= rhoFlush) {
+                float oP[kSwTk][4], oM[kSwTk][4];
 #pragma unroll
-                    for (int t = 0; t < 3; ++t)
+                for (int t = 0; t < kSwTk; ++t)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) { oP[t][r] = outP[r * kSwPitch + 16 * (t0 + t)]; oM[t][r] = outM[(3 - r) * kSwPitch + 16 * (t0 + t)]; }
+                    for (int r = 0; r < 4; ++r) { oP[t][r] = outP[r * kSwPitch + 16 * (t0 + t)]; oM[t][r] = outM[(3 - r) * kSwPitch + 16 * (t0 + t)]; }
 #pragma unroll
-                    for (int t = 0; t < 3; ++t)
+                for (int t = 0; t < kSwTk; ++t)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            outP[r * kSwPitch + 16 * (t0 + t)] = oP[t][r] + acc[t0 + t][r];
-                            if (r > 0 || kq > 0) outM[(3 - r) * kSwPitch + 16 * (t0 + t)] = oM[t][r] + acc[t0 + t][r];
-                        }
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        outP[r * kSwPitch + 16 * (t0 + t)] = oP[t][r] + acc[t0 + t][r];
+                        if (r > 0 || kq > 0) outM[(3 - r) * kSwPitch + 16 * (t0 + t)] = oM[t][r] + acc[t0 + t][r];
+                    }
             }
-            if (rhoFlush == kSwMaxR) {
+            if (rhoFlush == kSwMaxR) {                               // the row |dy| = 16: t16[h2] is column 64 h2 + lane; this group's columns only
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    const int c = lane + 64 * hf;
-                    if (c < kSwOut) {
-                        sOut[(ri + 2 * kSwMaxR) * kSwPitch + c] += t16[hf];
-                        sOut[ri * kSwPitch + c] += t16[hf];
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int c = lane + 64 * h2;
+                    if (c >= 16 * t0 && c < 16 * (t0 + kSwTk)) {
+                        sOut[(ri + 2 * kSwMaxR) * kSwPitch + c] += t16[h2];
+                        sOut[ri * kSwPitch + c] += t16[h2];
                     }
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the tile writes precede the ticket
+            if (lane == 0) __hip_atomic_store(&sTicket[t0 / kSwTk], ri + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // the tile writes precede the ticket
-        if (lane == 0) __hip_atomic_store(&sMisc[1], ri + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __builtin_amdgcn_s_setprio(0);
         if (dbg) { dbgWait += dw1 - dw0; dbgFlush += (long long)__builtin_amdgcn_s_memtime() - dw1; }
     }
