@@ -877,9 +877,11 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
                     f->dRSigma, (const float*)f->dRayWeights, (const int*)f->dFirstInside, (const int*)f->dFirstOutside,
                     f->dFirstPassive, f->dTileRad, f->dLayers, f->dState, h->lut, f->fillGeom, fc, (const float*)f->dStepTab, f->dActive, h->numCUs, f->dFillDbg, nucFill, f->dSigMin, f->dSigMax, tryUniform ? 1 : 0);
         };
-        const bool ldsLut = fillLds <= 40 * 1024;     // + ~17 KiB of static exchange arrays: stays under the 64 KiB default cap of a block's LDS
-        if (fc.nuclearCorr) { if (ldsLut) launchFill((k_fill<true, true>), fillLds); else launchFill((k_fill<false, true>), 0); }
-        else { if (ldsLut) launchFill((k_fill<true, false>), fillLds); else launchFill((k_fill<false, false>), 0); }
+        const bool ldsLut = fillLds <= 56 * 1024;     // (+ ~1 KiB of static arrays: stays under the 64 KiB default cap of a block's LDS)
+        constexpr size_t sigLds = (size_t)2 * kFillBatch * 256 * sizeof(float);   // the sigma walk's exchange buffers share the dynamic LDS with the dose walk's LUT rows
+        const size_t dynLds = std::max(sigLds, ldsLut ? fillLds : (size_t)0);
+        if (fc.nuclearCorr) { if (ldsLut) launchFill((k_fill<true, true>), dynLds); else launchFill((k_fill<false, true>), dynLds); }
+        else { if (ldsLut) launchFill((k_fill<true, false>), dynLds); else launchFill((k_fill<false, false>), dynLds); }
     }
     if (fc.nuclearCorr) {
         // the halo's plan runs first: its radius overflow (kernel_wrapper.cu:984) is reported in the primary state, which k_ks_plan mirrors

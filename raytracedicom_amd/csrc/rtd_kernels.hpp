@@ -843,7 +843,9 @@ __global__ __launch_bounds__(256) void k_fill(const float* __restrict__ bevDensi
                                                unsigned int* __restrict__ sigMin, unsigned int* __restrict__ sigMax, int trackUniform) {
     extern __shared__ float sLutF[];                                 // dose walk: the layer's two cumulative-IDD rows
     // diagnostic build only (RTD_FILL_DEBUG): per walk start / end clock, hardware id, item — no output value depends on it
-    __shared__ float sSig[2][kFillBatch][256];                       // sigma walk: [buffer][step][ray] sigmaSq of the rays with a finite 1/sigma (-1: none)
+    // sigma walk: [buffer][step][ray] sigmaSq of the rays with a finite 1/sigma (-1: none) — in the same dynamic LDS as the dose walk's
+    // LUT rows (a block is one or the other: 16 KB instead of 16 + 8, a seventh block per CU where the walks outnumber the slots)
+    float (*sSig)[kFillBatch][256] = reinterpret_cast<float (*)[kFillBatch][256]>(sLutF);
     __shared__ unsigned long long sDoseMask[2][kFillBatch][4];       // dose walk: [buffer][step][wave] ballot of the rays that carry dose
     __shared__ int sHist[kMaxSuperpR + 2];
     __shared__ int sClassLo[kMaxSuperpR + 2], sClassHi[kMaxSuperpR + 2];   // sigma walk: first / last step of this walk with a tile of that radius class
