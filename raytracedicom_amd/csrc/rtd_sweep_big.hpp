@@ -385,10 +385,8 @@ __global__ __launch_bounds__(64 * kSwWaves, 2) void k_superpose_sweep_big(const 
     float* out = bevDose + (size_t)k * bevW * bevH;
     const int bx0 = ux0 + kMaxSuperpR - kBgR, by0 = uy0 + kMaxSuperpR - kBgR;     // padded BEV pixel = ray + 32; tile pixel 0 = ray sx0 - 32
     const int bx1 = min(bx0 + kSwPatch * (nPX - 1) + kBgOut, bevW), by1 = min(by0 + kSwPatchRows * (nPY - 1) + kBgOutRows, bevH);   // exclusive
-    const int bw = bx1 - bx0, nIn = bw * (by1 - by0);
     // Tile by tile, as float4 through the L2 after an invalidate (the other blocks' tile stores went to the memory side: sc1); all
     // groups of four pixel quads are requested together — a chain of dependent loads from the memory side costs a round trip each.
-    (void)nIn; (void)bw;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     constexpr int kQ = kBgOut / 4;                                   // float4 per tile row
     constexpr int kU = 4;
