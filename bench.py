@@ -392,6 +392,8 @@ def main():
             torch.cuda.synchronize()
             assembled_check = bool(torch.equal(assembled, ref))
         # the headers of the messages this rank received carry the senders' device-side error flags: none may be set
+        # (attached here: a rank whose slab came out empty — a late rank gets none — has transferred nothing and attached nothing)
+        ex.attach_all(i_chk % 2)
         for f_r in ex.remote.values():
             f_r.finish()
         last.zero_()

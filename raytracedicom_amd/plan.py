@@ -193,6 +193,15 @@ class BevExchange:
                 f.attach_bev(base + r * self.cap)
                 f.transfer(dose_ptr, lo, hi)
 
+    def attach_all(self, b):
+        """Attach every other rank's message of receive buffer b to its remote field WITHOUT transferring anything — what a rank
+        whose slab is empty (complete() returns at once) needs before it can read the senders' headers (rtd_field_finish of a
+        remote field reports their device-side error flags)."""
+        base = self.data_ptr(self.recv[b])
+        for r in range(self.world):
+            if r != self.rank:
+                self.remote[r].attach_bev(base + r * self.cap)
+
     def _union_box(self, lo, hi):
         """Bounding box of all fields' dose boxes inside [lo, hi], or None."""
         valid = [bx for bx in self.boxes if all(bx[3 + a] >= bx[a] for a in range(3))]

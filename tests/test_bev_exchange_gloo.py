@@ -137,8 +137,11 @@ def _worker(rank, world, port, out_dir):
     remote = {r: _StandInField(scn.dims) for r in range(world) if r != rank}
     ex = plan.BevExchange(dist, rank, world, remote, scn.dims, new_bytes=lambda k: torch.empty(int(k), dtype=torch.uint8))
     # measured costs (bench.py supplies them): rank 1 pretends to own an expensive field -> thinner slab, same dose
-    ex.setup(own, head_us=700 + 300 * (rank == 1), transfer_ps_per_kvoxel=4000)
+    # (world 4: so expensive that its slab comes out EMPTY — it transfers nothing and attaches nothing)
+    ex.setup(own, head_us=700 + (300 if world < 4 else 50000) * (rank == 1), transfer_ps_per_kvoxel=4000)
     assert ex.cap % 256 == 0 and len(ex.ranges) == world
+    if world == 4:
+        assert ex.ranges[1][1] < ex.ranges[1][0]
     vols = [torch.zeros((n, n, n), dtype=torch.float32) for _ in range(2)]
     # three pipelined plans on two alternating volumes / buffers (bench.py's loop): post plan i, then complete plan i - 1
     pending = None
@@ -163,6 +166,11 @@ def _worker(rank, world, port, out_dir):
     mask = np.zeros_like(out, dtype=bool)
     mask[lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1] = True
     assert not out[~mask].any()                                       # nothing outside this rank's slab
+    # reading the senders' headers (bench.py's last check) needs the messages attached — also on a rank with an empty slab
+    if hi[ex.axis] < lo[ex.axis]:
+        assert all(fr.msg is None for fr in remote.values())
+    ex.attach_all(pending)
+    assert all(fr.msg is not None for fr in remote.values())
     np.save(os.path.join(out_dir, "slab%d.npy" % rank), out)
     dist.barrier()
     dist.destroy_process_group()
