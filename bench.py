@@ -94,6 +94,7 @@ def main():
                     help="N=1 only: run the N>1 code path (process group, all-gather, fused slab transfer) with a world of one rank — "
                          "exercises the RCCL calls on a one-GPU box; not a benchmark mode")
     ap.add_argument("--backend", default="nccl", help="process-group backend; 'gloo' only to rehearse N>1 on a one-GPU box")
+    ap.add_argument("--debug-head-us", default="", help=argparse.SUPPRESS)   # tests only: per-rank field times for the slab cut, e.g. "600,90000" (rank 1 gets an empty slab)
     args = ap.parse_args()
 
     # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as a CHILD process (this process has made no
@@ -184,6 +185,8 @@ def main():
                 ps_kvox.append(1.25 * t_j["transforming_ms"] * 1e9 / t_j["transfer_voxels"] * 1000.0)   # + 25 %: the clear of the box
         doses[0].zero_()
         fld.compute_bev()
+        if args.debug_head_us:
+            head_us = [float(args.debug_head_us.split(",")[rank])]
         ex.setup(fld, head_us=min(head_us) if head_us else None, transfer_ps_per_kvoxel=min(ps_kvox) if ps_kvox else None)   # message capacity, dose boxes, slab partition: the fields keep their geometry
         fld.finish()
     main_stream.synchronize()

@@ -408,8 +408,11 @@ def test_bench_exchange_path_under_rccl_with_one_rank():
     assert "all-gather" in r["config"]["exchange"] and r["value"] > 0
 
 
-def test_bench_launches_its_own_ranks_two_processes_one_gpu():
-    """`python bench.py --gpus 2` with no launcher in front: bench.py starts torch.distributed.run as a child process before it
+@pytest.mark.parametrize("cut", ["measured", "rank 1 gets an empty slab"])
+def test_bench_launches_its_own_ranks_two_processes_one_gpu(cut):
+    """(Second case: the slab cut is told that rank 1's field is hopelessly late, so its slab holds nothing that any field's dose box reaches (or is empty) — it
+    transfers nothing and attaches nothing; the eight-field plan has such a rank — and the run must still produce its line, checks included.)
+    `python bench.py --gpus 2` with no launcher in front: bench.py starts torch.distributed.run as a child process before it
     touches the GPU and relays rank 0's line. Two ranks share this box's one GPU over gloo (the RCCL world needs one GPU per rank):
     the N>1 path with two real ranks — two slabs gathered, each rank writing its slab with both fields. The slabs together hold the
     sum of the fields (reduce_check), a reused volume is clean (clear_check), and the volume assembled on rank 0 equals the
@@ -421,7 +424,8 @@ def test_bench_launches_its_own_ranks_two_processes_one_gpu():
     from conftest import ROOT
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--size", "128", "--steps", "4",
-                        "--warmup", "2", "--no-cpu"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+                        "--warmup", "2", "--no-cpu"] + ([] if cut == "measured" else ["--debug-head-us", "600,90000"]),
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
@@ -429,6 +433,10 @@ def test_bench_launches_its_own_ranks_two_processes_one_gpu():
     assert r["n_gpus"] == 2 and r["steps"] == 4 and r["scaling"] == "weak"
     assert r["reduce_check_rel_err"] < 1e-9 and r["clear_check"] is True and r["assembled_check"] is True
     assert r["value"] > 0 and "all-gather" in r["config"]["exchange"]
+    if cut != "measured":       # rank 1 is left with the rows no field's dose box reaches (or none): nothing to transfer there
+        import re
+        m = re.search(r"ranges \[\((\d+), (\d+)\), \((\d+), (-?\d+)\)\]", r["config"]["exchange"])
+        assert m and int(m.group(4)) - int(m.group(3)) + 1 <= 16, r["config"]["exchange"]
 
 
 @pytest.mark.parametrize("angles", [(0.0,), (90.0, 37.0, 200.0)])
