@@ -102,6 +102,7 @@ struct rtd_field_impl {
     int* dNodeCount = nullptr;   // [output tile][step][32] arrival counters of the superposition's reduction tree (all zero between launches)
     int *dFirstInside = nullptr, *dFirstOutside = nullptr, *dFirstPassive = nullptr, *dWeplMin = nullptr;
     float* dBlockWeplMin = nullptr;   // [R/64][S] per scan block and step: smallest WEPL of the block's 64 rays
+    KsPlanArgs* dKsArgs = nullptr;    // the plan's arguments for a launch that plans for itself (k_superpose_sweep<true>): written at each such launch
     float* dSegPos = nullptr;         // [S / kTraceSeg + 1][3][R] sample positions at the segment boundaries of k_trace_sample (walked once, at creation)
     unsigned char* dTileRad = nullptr;
     size_t tileRadWords = 0;
@@ -131,6 +132,7 @@ struct rtd_field_impl {
     FieldState* dHostState = nullptr;
     std::vector<LayerPlan> hLayers;
     hipEvent_t ev[9] = {};       // 0..6 stage ends, 7 / 8 stop / start of k_superpose_mfma
+    bool selfPlanned = false;    // the last compute had no k_ks_plan launch: block 0 of k_superpose_sweep's launch was the plan (ev[4] not recorded)
     bool computed = false;       // the BEV dose and the state record of the last rtd_field_compute[_bev] exist (or a slab is attached)
     bool transferred = false;    // a transfer has been launched since (ev[6] is recorded)
     bool remote = false;         // geometry only: the BEV slab comes from another GPU (rtd_field_attach_bev)
@@ -489,7 +491,7 @@ int rtd_field_destroy(rtd_handle hh, rtd_field ff) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = { f->dSpotWeights, f->dConvInterm, f->dRayWeights, f->dDensity, f->dWepl, f->dRrl, f->dIdd, f->dRSigma, f->dBev, f->dBevPart, f->dNodeCount, f->dSwSlots, f->dSwCount, f->dSwSlotsBig, f->dSwCountBig,
-                     f->dFirstInside, f->dFirstOutside, f->dFirstPassive, f->dWeplMin, f->dBlockWeplMin, f->dSegPos, f->dTileRad,
+                     f->dFirstInside, f->dFirstOutside, f->dFirstPassive, f->dWeplMin, f->dBlockWeplMin, f->dSegPos, f->dKsArgs, f->dTileRad,
                      f->dLayers, f->dState, f->dStepTab, f->dActive, f->dSigMin, f->dSigMax, f->dFillDbg, f->dSweepDbg, f->dSweepBigDbg, f->dScanDbg,
                      f->dNucSpotIdx, f->dNucRayWeights, f->dNucIdd, f->dNucRs, f->dNucBev, f->dNucEffT, f->dStateNuc };
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -652,7 +654,7 @@ static int createField(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dim
         f->dSpotWeights = husk->dSpotWeights; f->dConvInterm = husk->dConvInterm; f->dRayWeights = husk->dRayWeights;
         f->dDensity = husk->dDensity; f->dWepl = husk->dWepl; f->dRrl = husk->dRrl; f->dIdd = husk->dIdd; f->dRSigma = husk->dRSigma;
         f->dBev = husk->dBev; f->dBevPart = husk->dBevPart; f->dNodeCount = husk->dNodeCount; f->dSwSlots = husk->dSwSlots; f->dSwCount = husk->dSwCount; f->dSwSlotsBig = husk->dSwSlotsBig; f->dSwCountBig = husk->dSwCountBig; f->dFirstInside = husk->dFirstInside; f->dFirstOutside = husk->dFirstOutside;
-        f->dFirstPassive = husk->dFirstPassive; f->dWeplMin = husk->dWeplMin; f->dBlockWeplMin = husk->dBlockWeplMin; f->dSegPos = husk->dSegPos; f->dTileRad = husk->dTileRad; f->dLayers = husk->dLayers;
+        f->dFirstPassive = husk->dFirstPassive; f->dWeplMin = husk->dWeplMin; f->dBlockWeplMin = husk->dBlockWeplMin; f->dSegPos = husk->dSegPos; f->dKsArgs = husk->dKsArgs; f->dTileRad = husk->dTileRad; f->dLayers = husk->dLayers;
         f->dState = husk->dState; f->dStepTab = husk->dStepTab; f->dActive = husk->dActive; f->dSigMin = husk->dSigMin; f->dSigMax = husk->dSigMax; f->hState = husk->hState; f->dHostState = husk->dHostState;
         for (int i = 0; i < 9; ++i) f->ev[i] = husk->ev[i];
         delete husk;
@@ -668,7 +670,7 @@ static int createField(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dim
         A(&f->dSwSlots, (size_t)S * f->swPX * f->swPY * f->swGroups * kSwSlot); A(&f->dSwCount, (size_t)S);
         A(&f->dSwSlotsBig, (size_t)S * f->swPX * f->swPY * f->bgGroups * kBgSlot); A(&f->dSwCountBig, (size_t)S);
     }
-    A(&f->dFirstInside, R); A(&f->dFirstOutside, R); A(&f->dFirstPassive, R * L); A(&f->dWeplMin, (size_t)S); A(&f->dBlockWeplMin, (R / 64) * (size_t)S); A(&f->dSegPos, ((size_t)S / kTraceSeg + 1) * 3 * R);
+    A(&f->dFirstInside, R); A(&f->dFirstOutside, R); A(&f->dFirstPassive, R * L); A(&f->dWeplMin, (size_t)S); A(&f->dBlockWeplMin, (R / 64) * (size_t)S); A(&f->dSegPos, ((size_t)S / kTraceSeg + 1) * 3 * R); A(&f->dKsArgs, (size_t)1);
     A(&f->dTileRad, f->tileRadWords * 4); A(&f->dLayers, (size_t)L); A(&f->dState, (size_t)1); A(&f->dStepTab, (size_t)2 * S); A(&f->dActive, (size_t)4 * L * S); A(&f->dSigMin, (size_t)L * S); A(&f->dSigMax, (size_t)L * S);
     if (st != RTD_OK) { rtd_field_destroy(hh, reinterpret_cast<rtd_field>(f)); return st; }
     hipError_t e = hipMemcpy(f->dSpotWeights, b->spot_weights, nSpot * sizeof(float), hipMemcpyHostToDevice);   // :851
@@ -682,6 +684,12 @@ static int createField(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dim
     if (e == hipSuccess && fresh) e = hipHostMalloc((void**)&f->hState, sizeof(FieldState), hipHostMallocMapped);
     if (e == hipSuccess && fresh) e = hipHostGetDevicePointer((void**)&f->dHostState, f->hState, 0);
     if (e == hipSuccess) std::memset(f->hState, 0, sizeof(FieldState));
+    if (e == hipSuccess) {   // the plan's arguments as a self-planning sweep launch reads them (constant for the field: such a launch never tries the uniform path)
+        const KsPlanArgs ksSelf{f->dState, f->dLayers, f->rayIdxToDoseIdx, f->transfer0, (int)f->doseDims[0], (int)f->doseDims[1], (int)f->doseDims[2],
+                                f->ksGroups, f->swGroups, f->dHostState, nullptr, (const unsigned int*)f->dSigMin, (const unsigned int*)f->dSigMax,
+                                0, f->sweepEnabled ? kSwMaxR : -1, f->bgGroups};
+        e = hipMemcpy(f->dKsArgs, &ksSelf, sizeof ksSelf, hipMemcpyHostToDevice);
+    }
     {
         std::vector<float> tab(2 * (size_t)S);
         for (int k = 0; k < S; ++k) {
@@ -888,9 +896,14 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
         k_nuc_plan<<<1, 256, 0, s>>>(f->dState, f->dStateNuc, (const LayerPlan*)f->dLayers, (const float*)f->dNucRs, f->dNucEffT, fc,
                                      f->nucIdxToDoseIdx, f->transfer0Nuc, (int)f->doseDims[0], (int)f->doseDims[1], (int)f->doseDims[2]);
     }
-    launchK(k_ks_plan, dim3(1), dim3(256), 0, s, nullptr, f->ev[4], f->dState, f->dLayers, fc, f->rayIdxToDoseIdx, f->transfer0,
-                          (int)f->doseDims[0], (int)f->doseDims[1], (int)f->doseDims[2], f->ksGroups, f->swGroups, f->dHostState, f->dStateNuc,
-                          (const unsigned int*)f->dSigMin, (const unsigned int*)f->dSigMax, tryUniform ? 1 : 0, f->sweepEnabled ? kSwMaxR : -1, f->bgGroups);
+    const KsPlanArgs ksArgs{f->dState, f->dLayers, f->rayIdxToDoseIdx, f->transfer0, (int)f->doseDims[0], (int)f->doseDims[1], (int)f->doseDims[2],
+                            f->ksGroups, f->swGroups, f->dHostState, f->dStateNuc, (const unsigned int*)f->dSigMin, (const unsigned int*)f->dSigMax,
+                            tryUniform ? 1 : 0, f->sweepEnabled ? kSwMaxR : -1, f->bgGroups};
+    // Once the host knows that the field is not a uniform-sigma one (and without the halo), the sweep's launch plans for itself
+    // (k_superpose_sweep<true>: its block 0 is the plan): one launch and its gap less on the critical path.
+    const bool selfPlan = f->sweepEnabled && !tryUniform && !fc.nuclearCorr && std::getenv("RTD_SEPARATE_KS_PLAN") == nullptr;
+    f->selfPlanned = selfPlan;
+    if (!selfPlan) launchK(k_ks_plan, dim3(1), dim3(256), 0, s, nullptr, f->ev[4], ksArgs, fc);
     if (fc.nuclearCorr) {
         const int nPix = (fc.nucW + 2 * kMaxSuperpR) * (fc.nucH + 2 * kMaxSuperpR);
         k_nuc_superpose<<<(nPix + 255) / 256, 256, 0, s>>>((const float*)f->dNucIdd, (const float*)f->dNucRs, (const int*)f->dNucEffT,
@@ -936,18 +949,24 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
     const bool runMfma = !knownUniform && !f->sweepEnabled;
     if (runSweep) {
         constexpr size_t swLds = (size_t)kSwLdsWords * sizeof(float);
+        static_assert(sizeof(KsPlanLds) <= swLds, "the plan block's LDS is the front of the sweep's");
         if (!h->sweepLdsSet) {
-            RTD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_superpose_sweep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)swLds));
+            RTD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_superpose_sweep<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)swLds));
+            RTD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_superpose_sweep<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)swLds));
             h->sweepLdsSet = true;
         }
+        const unsigned nSwBlocks = (unsigned)(fc.S * f->swPX * f->swPY * f->swGroups) + (selfPlan ? 1u : 0u);
         if (!f->dSweepDbg && std::getenv("RTD_SWEEP_DEBUG")) {
-            f->sweepDbgN = (size_t)(8 + 4 * 16) * fc.S * f->swPX * f->swPY * f->swGroups;
+            f->sweepDbgN = (size_t)(8 + 4 * 16) * (fc.S * f->swPX * f->swPY * f->swGroups + 1);
             RTD_HIP(h, hipMalloc((void**)&f->dSweepDbg, f->sweepDbgN * sizeof(long long)));
             RTD_HIP(h, hipMemset(f->dSweepDbg, 0, f->sweepDbgN * sizeof(long long)));
         }
-        launchK(k_superpose_sweep, dim3((unsigned)(fc.S * f->swPX * f->swPY * f->swGroups)), dim3(64 * kSwWaves), swLds, s, ksStart, runBig ? nullptr : f->ev[5],
-                (const float*)f->dIdd, (const float*)f->dRSigma, (const unsigned char*)f->dTileRad, (const LayerPlan*)f->dLayers, (const FieldState*)f->dState, fc,
-                f->swGroups, f->swPX, f->swPY, (const int*)f->dActive, f->dSwSlots, f->dSwCount, f->dBev, f->dSweepDbg);
+        auto launchSweep = [&](auto kern) {
+            launchK(kern, dim3(nSwBlocks), dim3(64 * kSwWaves), swLds, s, ksStart, runBig ? nullptr : f->ev[5],
+                    (const float*)f->dIdd, (const float*)f->dRSigma, (const unsigned char*)f->dTileRad, (const LayerPlan*)f->dLayers, (const FieldState*)f->dState, fc,
+                    f->swGroups, f->swPX, f->swPY, (const int*)f->dActive, f->dSwSlots, f->dSwCount, f->dBev, f->dSweepDbg, (const KsPlanArgs*)f->dKsArgs);
+        };
+        if (selfPlan) launchSweep(k_superpose_sweep<true>); else launchSweep(k_superpose_sweep<false>);
         ksStart = nullptr;
     }
     if (runBig) {
@@ -1135,8 +1154,8 @@ int rtd_field_wait_plan(rtd_handle hh, rtd_field ff, rtd_field_info* info, size_
     if (!h || !f) return RTD_ERR_INVALID_ARG;
     if (!f->computed || f->remote) return fail(h, RTD_ERR_NOT_READY, "rtd_field_wait_plan: field not computed on this handle");
     RTD_HIP(h, hipSetDevice(h->device));
-    RTD_HIP(h, hipEventSynchronize(f->ev[4]));
-    const FieldState st = *f->hState;                                // mirrored by k_ks_plan into pinned host memory
+    RTD_HIP(h, hipEventSynchronize(f->selfPlanned ? f->ev[5] : f->ev[4]));   // (a launch that planned for itself: its plan is complete when the superposition is)
+    const FieldState st = *f->hState;                                // mirrored by the plan into pinned host memory
     // (the finding belongs to the inputs the compute was LAUNCHED under: CT, LUTs or options may have changed since)
     if (f->triedUniform) { f->uniformHint = st.uniformField ? 1 : 0; f->hintEpoch = f->launchEpoch; }
     else if (f->hintEpoch != f->launchEpoch) { f->uniformHint = -1; f->hintEpoch = f->launchEpoch; }
@@ -1225,8 +1244,9 @@ int rtd_field_finish(rtd_handle hh, rtd_field ff, rtd_timing* timing, rtd_field_
             RTD_HIP(h, hipEventElapsedTime(&timing->raytracing_ms, f->ev[0], f->ev[1]));
             RTD_HIP(h, hipEventElapsedTime(&timing->prepare_energy_loop_ms, f->ev[1], f->ev[2]));
             RTD_HIP(h, hipEventElapsedTime(&timing->fill_idd_sigma_ms, f->ev[2], f->ev[3]));
-            RTD_HIP(h, hipEventElapsedTime(&timing->prepare_superp_ms, f->ev[3], f->ev[4]));
-            RTD_HIP(h, hipEventElapsedTime(&timing->superp_ms, f->ev[4], f->ev[5]));
+            hipEvent_t planEnd = f->selfPlanned ? f->ev[8] : f->ev[4];   // (self-planned: the plan is inside the superposition launch)
+            RTD_HIP(h, hipEventElapsedTime(&timing->prepare_superp_ms, f->ev[3], planEnd));
+            RTD_HIP(h, hipEventElapsedTime(&timing->superp_ms, planEnd, f->ev[5]));
             RTD_HIP(h, hipEventElapsedTime(&timing->superp_kernel_ms, f->ev[8], f->ev[5]));
             if (f->transferred) RTD_HIP(h, hipEventElapsedTime(&timing->transforming_ms, f->ev[5], f->ev[6]));
         }

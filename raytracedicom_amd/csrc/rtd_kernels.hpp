@@ -1182,21 +1182,57 @@ __device__ inline void transferBoxes(const FromFan& rayIdxToDoseIdx, int W, int 
 // ------------------------------------------------------------------------------------------------
 // K6: superposition plan = host batching of radii (kernel_wrapper.cu:965-976) + beamFirstCalculatedPassive
 // (:955-957) + transfer bounding box and shift (:1185-1213), all on the device.
-__global__ __launch_bounds__(256) void k_ks_plan(FieldState* stGlobal, LayerPlan* layers, FieldConst fc, FromFan rayIdxToDoseIdx, TransferParams tp0,
-                                                 int doseNx, int doseNy, int doseNz, int G, int Gs, FieldState* __restrict__ hostMirror,
-                                                 FieldState* __restrict__ stNuc, const unsigned int* __restrict__ sigMin,
-                                                 const unsigned int* __restrict__ sigMax, int uniformEligible, int sweepMaxR, int Gb) {
-    const int tid = threadIdx.x, nT = blockDim.x;
+struct KsPlanArgs {
+    FieldState* stGlobal; LayerPlan* layers; FromFan rayIdxToDoseIdx; TransferParams tp0;
+    int doseNx, doseNy, doseNz, G, Gs;
+    FieldState* hostMirror; FieldState* stNuc;
+    const unsigned int* sigMin; const unsigned int* sigMax;
+    int uniformEligible, sweepMaxR, Gb;
+};
+// The batching rule of one layer (kernel_wrapper.cu:966-976): batch radius per radius class from the layer's class histogram; returns
+// the largest class present. Used by the plan (which records the result) and by k_superpose_sweep's blocks when they plan for themselves.
+__device__ inline int batchRadii(const int (&hist)[kMaxSuperpR + 2], int (&effRad)[kMaxSuperpR + 2]) {
+    int layerMax = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxSuperpR + 2; ++i) { if (hist[i] > 0) layerMax = i; effRad[i] = i; }
+    // tiles at steps >= layerFirstPassive are not classified by the reference; they can only be radius 0
+    if (layerMax <= kMaxSuperpR) {
+        int rec = layerMax, batched = 0;
+#pragma unroll
+        for (int rad = kMaxSuperpR; rad > 0; --rad) {
+            if (rad <= layerMax) {
+                batched += hist[rad];
+                effRad[rad] = rec;
+                if (batched >= kMinTilesInBatch) { rec = rad - 1; batched = 0; }
+            }
+        }
+    }
+    return layerMax;
+}
+// The block's LDS (k_ks_plan: static; as block 0 of k_superpose_sweep's launch: the front of that kernel's dynamic LDS, so that its
+// blocks' footprint — two per CU — does not grow)
+struct KsPlanLds {
+    FieldState st;
+    unsigned long long live;
+    int maxPassive, maxRad, sliceDiffers;
+    int group[32], groupSw[16], bigLo[16], bigHi[16];
+    int area[kKsMaxOrder];
+};
+// One block of nT threads (a launch of its own, k_ks_plan, or block 0 of k_superpose_sweep's launch — rtd_sweep.hpp).
+__device__ inline void ksPlanBody(const KsPlanArgs& ka, const FieldConst& fc, const int tid, const int nT, KsPlanLds& L_) {
+    FieldState* stGlobal = ka.stGlobal; LayerPlan* layers = ka.layers;
+    const FromFan& rayIdxToDoseIdx = ka.rayIdxToDoseIdx; const TransferParams& tp0 = ka.tp0;
+    const int doseNx = ka.doseNx, doseNy = ka.doseNy, doseNz = ka.doseNz, G = ka.G, Gs = ka.Gs;
+    FieldState* hostMirror = ka.hostMirror; FieldState* stNuc = ka.stNuc;
+    const unsigned int* sigMin = ka.sigMin; const unsigned int* sigMax = ka.sigMax;
+    const int uniformEligible = ka.uniformEligible, sweepMaxR = ka.sweepMaxR, Gb = ka.Gb;
     // The state record is completed in LDS and then written out — to device memory and to its pinned host mirror — by all threads,
     // one dword each per trip: this one-block launch sits on the field's critical path, and both a load of the record behind a
     // store to it and a serial copy over PCIe by one thread cost microseconds each.
-    __shared__ FieldState sSt;
-    __shared__ int sMaxPassive;
-    __shared__ int sGroup[32], sGroupSw[16];
-    __shared__ int sBigLo[16], sBigHi[16];
-    __shared__ int sMaxRad;
-    __shared__ unsigned long long sLive;
-    __shared__ int sSliceDiffers;
+    FieldState& sSt = L_.st;
+    int& sMaxPassive = L_.maxPassive; int& sMaxRad = L_.maxRad; int& sSliceDiffers = L_.sliceDiffers;
+    unsigned long long& sLive = L_.live;
+    int (&sGroup)[32] = L_.group; int (&sGroupSw)[16] = L_.groupSw; int (&sBigLo)[16] = L_.bigLo; int (&sBigHi)[16] = L_.bigHi;
     {
         const unsigned int* src = reinterpret_cast<const unsigned int*>(stGlobal);
         unsigned int* dst = reinterpret_cast<unsigned int*>(&sSt);
@@ -1215,22 +1251,8 @@ __global__ __launch_bounds__(256) void k_ks_plan(FieldState* stGlobal, LayerPlan
 #pragma unroll
         for (int i = 0; i < kMaxSuperpR + 2; ++i) hist[i] = p.hist[i];
         const int lfp = p.layerFirstPassive;
-        int layerMax = 0;
-#pragma unroll
-        for (int i = 0; i < kMaxSuperpR + 2; ++i) { if (hist[i] > 0) layerMax = i; effRad[i] = i; }
-        // tiles at steps >= layerFirstPassive are not classified by the reference; they can only be radius 0
+        const int layerMax = batchRadii(hist, effRad);
         if (hist[kMaxSuperpR + 1] > 0) atomicOr(&st->errorFlags, kErrRadiusOverflow);
-        if (layerMax <= kMaxSuperpR) {
-            int rec = layerMax, batched = 0;
-#pragma unroll
-            for (int rad = kMaxSuperpR; rad > 0; --rad) {
-                if (rad <= layerMax) {
-                    batched += hist[rad];
-                    effRad[rad] = rec;
-                    if (batched >= kMinTilesInBatch) { rec = rad - 1; batched = 0; }
-                }
-            }
-        }
 #pragma unroll
         for (int i = 0; i < kMaxSuperpR + 2; ++i) p.effRad[i] = effRad[i];
         atomicMax(&sMaxRad, layerMax);
@@ -1273,7 +1295,7 @@ __global__ __launch_bounds__(256) void k_ks_plan(FieldState* stGlobal, LayerPlan
     {   // Output tiles of the superposition ranked by the number of dose-carrying rays within reach: the work items of the
         // busiest tiles are dispatched first, the items of margin tiles (short) last, so the kernel does not end on a few
         // long items. One tile per thread, stable rank by counting.
-        __shared__ int sArea[kKsMaxOrder];
+        int (&sArea)[kKsMaxOrder] = L_.area;
         const int nTX = (fc.bevW + kKsTileX - 1) / kKsTileX, nTY = (fc.bevH + kKsTileY - 1) / kKsTileY, n = nTX * nTY;
         if (n <= kKsMaxOrder) {                                      // (kKsMaxOrder <= nT)
             const int rr = min(sMaxRad, kMaxSuperpR), t = tid;
@@ -1333,6 +1355,10 @@ __global__ __launch_bounds__(256) void k_ks_plan(FieldState* stGlobal, LayerPlan
         // NUCLEAR_CORR: a radius overflow of the primary field stops the halo's transfer as well
         if (stNuc && tid == 0 && sSt.errorFlags) stNuc->errorFlags = sSt.errorFlags;
     }
+}
+__global__ __launch_bounds__(256) void k_ks_plan(KsPlanArgs ka, FieldConst fc) {
+    __shared__ KsPlanLds lds;
+    ksPlanBody(ka, fc, threadIdx.x, blockDim.x, lds);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -217,12 +217,24 @@ __device__ inline void swLevelRun(f32x4 (&acc)[kSwNCB], const float* __restrict_
     swLevelRunQ<NEED, 8, kSwQCut>(acc, lds, idxA, ix);
     if (tail) swLevelRunQ<NEED, kSwQCut, 16>(acc, lds, idxA, ix);
 }
+// SELF: the launch plans for itself — no k_ks_plan in front. Block 0 IS the plan (ksPlanBody: the state record, the batch radii, the
+// boxes of the transfer — what the launches behind this one read), and every other block derives what IT needs from k_fill's results:
+// the steps its group deposits at and the field's last one from the layers' layerFirstPassive, the batch radii of its own layers from
+// their class histograms (batchRadii, the plan's own function), a radius overflow from the histograms' last bin. One launch and its
+// gap less on the field's critical path (k_ks_plan 11.8 us + 4.7 us). The host chooses SELF once a finished compute has told it that
+// the field is not a uniform-sigma one (the separable kernel sits between the plan and this launch otherwise); no NUCLEAR_CORR.
+template <bool SELF>
 __global__ __launch_bounds__(64 * kSwWaves, 4) void k_superpose_sweep(const float* __restrict__ bevIdd, const float* __restrict__ bevRSigmaEff,
                                                                    const unsigned char* __restrict__ tileRad, const LayerPlan* __restrict__ layers,
                                                                    const FieldState* __restrict__ st, FieldConst fc, int G, int nPXg, int nPYg,
                                                                    const int* __restrict__ active, float* __restrict__ slots, int* __restrict__ counters,
-                                                                   float* __restrict__ bevDose, long long* __restrict__ dbg) {
+                                                                   float* __restrict__ bevDose, long long* __restrict__ dbg, const KsPlanArgs* __restrict__ kaSelf) {
     extern __shared__ float sw[];
+    if (SELF && blockIdx.x == 0) {                                   // (dispatched first; its arguments in device memory: by value they
+        //  would sit in every block's registers — or scratch — for nothing)
+        ksPlanBody(*kaSelf, fc, (int)threadIdx.x, 64 * kSwWaves, *reinterpret_cast<KsPlanLds*>(sw));
+        return;
+    }
     // diagnostic build only (RTD_SWEEP_DEBUG): clock stamps per block — no output value depends on them
     const long long dbgT0 = dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
     long long dbgT1 = 0, dbgT2 = 0, dbgT3 = 0;
@@ -237,13 +249,42 @@ __global__ __launch_bounds__(64 * kSwWaves, 4) void k_superpose_sweep(const floa
     // (group fastest, then step, patch slowest: the live blocks — steps [entry, passive) of the patches that hold dose — are then
     //  CONSECUTIVE block indices, which the dispatcher deals round-robin to the 8 XCDs. With the patch index in the middle the
     //  live blocks of the bench field, one patch of four, all had indices 16 j + 0..3 and landed on four of the eight XCDs.)
-    int item = blockIdx.x;
+    int item = SELF ? (int)blockIdx.x - 1 : (int)blockIdx.x;
     const int g = item % G; item /= G;
     const int nPg = nPXg * nPYg;
     const int k = fc.S - 1 - item % fc.S; item /= fc.S;
     const int p = item;
-    if (st->errorFlags || st->uniformField) return;                  // radius overflow / water field
-    const int first = st->beamFirstInside, calcPassive = st->firstCalculatedPassive;
+    __shared__ int sPlan[2 + kSwMaxGroups];                          // SELF: the field's last depositing step + 1, radius overflow, the groups' last steps + 1
+    __shared__ unsigned short sLfp[SELF ? kMaxLayers : 1];           // SELF: layerFirstPassive of every layer
+    int* sEffRad = reinterpret_cast<int*>(sw);                       // SELF: [layer of the group][34] batch radius per class, in the tile's LDS before it is zeroed
+    if (SELF) {
+        // one round trip for everything the block plans from: every layer's last step (threads 0 .. L - 1) and the class histograms of
+        // the group's layers (threads 256 ...), batched with the plan's own function
+        if (tid < 2 + kSwMaxGroups) sPlan[tid] = 0;
+        __syncthreads();
+        for (int l = tid; l < fc.L; l += 64 * kSwWaves) {
+            const int lfp = layers[l].layerFirstPassive;
+            sLfp[l] = (unsigned short)lfp;
+            atomicMax(&sPlan[0], lfp);
+            atomicMax(&sPlan[2 + l % G], lfp);
+            if (layers[l].hist[kMaxSuperpR + 1] > 0) sPlan[1] = 1;
+        }
+        if (tid >= 256 && tid < 256 + kSwMaxLay) {
+            const int l = g + G * (tid - 256);
+            if (l < fc.L) {
+                int hist[kMaxSuperpR + 2], effRad[kMaxSuperpR + 2];
+#pragma unroll
+                for (int i = 0; i < kMaxSuperpR + 2; ++i) hist[i] = layers[l].hist[i];
+                batchRadii(hist, effRad);
+#pragma unroll
+                for (int i = 0; i < kMaxSuperpR + 2; ++i) sEffRad[(tid - 256) * (kMaxSuperpR + 2) + i] = effRad[i];
+            }
+        }
+        __syncthreads();
+    }
+    auto groupPassive = [&](int g2) { return SELF ? sPlan[2 + g2] : st->swGroupPassive[g2]; };
+    if (st->errorFlags || (SELF ? sPlan[1] != 0 : st->uniformField != 0)) return;   // radius overflow / water field
+    const int first = st->beamFirstInside, calcPassive = SELF ? sPlan[0] : st->firstCalculatedPassive;
     if (k < first || k >= calcPassive) return;
     // the rectangle of rays that carry dose anywhere in the field, cut into 64 x 64 patches from its own corner
     int ux0 = st->actUnion[0], uy0 = st->actUnion[1], ux1 = -st->actUnion[2], uy1 = -st->actUnion[3];
@@ -251,7 +292,7 @@ __global__ __launch_bounds__(64 * kSwWaves, 4) void k_superpose_sweep(const floa
     const int nPX = (ux1 - ux0) / kSwPatch + 1, nPY = (uy1 - uy0) / kSwPatchRows + 1;
     const int ppx = p % nPXg, ppy = p / nPXg;
     if (ppx >= nPX || ppy >= nPY) return;
-    if (k >= st->swGroupPassive[g]) return;                          // no layer of this group deposits at k
+    if (k >= groupPassive(g)) return;                                // no layer of this group deposits at k
     const int sx0 = ux0 + kSwPatch * ppx, sy0 = uy0 + kSwPatchRows * ppy;
     const int nRows = min(kSwPatchRows, uy1 - sy0 + 1), nCols = min(kSwPatch, ux1 - sx0 + 1);
     const int W = fc.W, H = fc.H, S = fc.S;
@@ -261,7 +302,7 @@ __global__ __launch_bounds__(64 * kSwWaves, 4) void k_superpose_sweep(const floa
     // ---- the group's layers that deposit at k, ascending; their dose-carrying rows inside the patch ----
     if (wv == 0) {
         const int l = g + G * lane;
-        const bool on = l < fc.L && k < layers[l].layerFirstPassive;
+        const bool on = l < fc.L && k < (SELF ? (int)sLfp[min(l, fc.L - 1)] : layers[l].layerFirstPassive);
         const unsigned long long mask = __ballot(on);
         if (on) {
             const int j = __popcll(mask & ((1ull << lane) - 1ull));
@@ -276,12 +317,29 @@ __global__ __launch_bounds__(64 * kSwWaves, 4) void k_superpose_sweep(const floa
         if (lane == 0) sMisc[0] = __popcll(mask);
         if (lane < kSwNCB / kSwTk) sTicket[lane] = 0;
     }
+    if (SELF) {
+        __syncthreads();
+        const int nL = sMisc[0];
+        for (int i = tid; i < nL * kSwTileRows * kSwTileCols; i += 64 * kSwWaves) {
+            const int j = i / (kSwTileRows * kSwTileCols), c = i % (kSwTileRows * kSwTileCols);
+            const int ty = ty0 + c / kSwTileCols, tx = tx0 + c % kSwTileCols;
+            int r = -1;
+            if (ty < fc.tilesY && tx < fc.tilesX) {
+                const int l = sLay[j];
+                const int own = tileRad[((size_t)l * S + k) * nTiles + ty * fc.tilesX + tx];
+                if (own <= kMaxSuperpR) r = sEffRad[((l - g) / G) * (kMaxSuperpR + 2) + own];
+                if (r > kSwMaxR) r = -1;                             // the second launch's
+            }
+            sEff[i] = (signed char)r;
+        }
+        __syncthreads();                                             // the tables are consumed: the tile may be zeroed
+    }
     for (int i = tid; i < kSwOutRows * kSwPitch; i += 64 * kSwWaves) sOut[i] = 0.0f;
     float* tab = sw + kSwLdsTab + wv * kSwWaveLds;
     for (int i = lane; i < kSwWaveLds; i += 64) tab[i] = 0.0f;       // guards (and everything the lookups may reach before it is written)
     __syncthreads();
     const int nLay = sMisc[0];
-    for (int i = tid; i < nLay * kSwTileRows * kSwTileCols; i += 64 * kSwWaves) {
+    for (int i = tid; !SELF && i < nLay * kSwTileRows * kSwTileCols; i += 64 * kSwWaves) {
         const int j = i / (kSwTileRows * kSwTileCols), c = i % (kSwTileRows * kSwTileCols);
         const int ty = ty0 + c / kSwTileCols, tx = tx0 + c % kSwTileCols;
         int r = -1;
@@ -434,7 +492,7 @@ __global__ __launch_bounds__(64 * kSwWaves, 4) void k_superpose_sweep(const floa
     __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0)
     __syncthreads();
     int nLiveG = 0;
-    for (int g2 = 0; g2 < G; ++g2) nLiveG += k < st->swGroupPassive[g2] ? 1 : 0;
+    for (int g2 = 0; g2 < G; ++g2) nLiveG += k < groupPassive(g2) ? 1 : 0;
     const int expected = nLiveG * nPX * nPY;
     if (tid == 0) {
         int last = 1;
@@ -480,7 +538,7 @@ __global__ __launch_bounds__(64 * kSwWaves, 4) void k_superpose_sweep(const floa
                     for (int gg = 0; gg < 4; ++gg)
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
-                            const bool on = g0 + gg < G && k < st->swGroupPassive[min(g0 + gg, G - 1)] && idx[u] >= 0;
+                            const bool on = g0 + gg < G && k < groupPassive(min(g0 + gg, G - 1)) && idx[u] >= 0;
                             v[gg][u] = on ? *reinterpret_cast<const float4*>(sl + (size_t)(g0 + gg) * kSwSlot + 4 * idx[u]) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                         }
 #pragma unroll
@@ -527,7 +585,7 @@ __global__ __launch_bounds__(64 * kSwWaves, 4) void k_superpose_sweep(const floa
                         for (int gg = 0; gg < 4; ++gg)
 #pragma unroll
                             for (int u = 0; u < kU; ++u) {
-                                const bool on = g0 + gg < G && k < st->swGroupPassive[min(g0 + gg, G - 1)] && off[u] >= 0;
+                                const bool on = g0 + gg < G && k < groupPassive(min(g0 + gg, G - 1)) && off[u] >= 0;
                                 v[gg][u] = on ? __hip_atomic_load(sl + (size_t)(g0 + gg) * kSwSlot + off[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
                             }
 #pragma unroll
