@@ -1223,8 +1223,8 @@ __device__ inline void ksPlanBody(const KsPlanArgs& ka, const FieldConst& fc, co
     FieldState* stGlobal = ka.stGlobal; LayerPlan* layers = ka.layers;
     const FromFan& rayIdxToDoseIdx = ka.rayIdxToDoseIdx; const TransferParams& tp0 = ka.tp0;
     const int doseNx = ka.doseNx, doseNy = ka.doseNy, doseNz = ka.doseNz, G = ka.G, Gs = ka.Gs;
-    FieldState* hostMirror = ka.hostMirror; FieldState* stNuc = ka.stNuc;
-    const unsigned int* sigMin = ka.sigMin; const unsigned int* sigMax = ka.sigMax;
+    FieldState* __restrict__ hostMirror = ka.hostMirror; FieldState* __restrict__ stNuc = ka.stNuc;
+    const unsigned int* __restrict__ sigMin = ka.sigMin; const unsigned int* __restrict__ sigMax = ka.sigMax;   // (restrict: the loads of the uniformity test stay in flight together)
     const int uniformEligible = ka.uniformEligible, sweepMaxR = ka.sweepMaxR, Gb = ka.Gb;
     // The state record is completed in LDS and then written out — to device memory and to its pinned host mirror — by all threads,
     // one dword each per trip: this one-block launch sits on the field's critical path, and both a load of the record behind a
@@ -1285,9 +1285,12 @@ __device__ inline void ksPlanBody(const KsPlanArgs& ka, const FieldConst& fc, co
         for (int i0 = tid; i0 < n; i0 += 4 * nT) {
             unsigned int a[4], b[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int i = i0 + u * nT; a[u] = i < n ? sigMin[i] : 0x7f800000u; b[u] = i < n ? sigMax[i] : 0u; }
+            for (int u = 0; u < 4; ++u) {                            // (unconditional loads from a clamped index: all eight in flight together)
+                const int ii = min(i0 + u * nT, n - 1);
+                a[u] = sigMin[ii]; b[u] = sigMax[ii];
+            }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) if (a[u] != 0x7f800000u && a[u] != b[u]) differs = 1;   // (+inf: no live ray)
+            for (int u = 0; u < 4; ++u) if (a[u] != 0x7f800000u && a[u] != b[u]) differs = 1;   // (+inf: no live ray; a repeated last entry changes nothing)
         }
         if (differs) atomicOr(&sSliceDiffers, 1);
     }
