@@ -27,7 +27,7 @@ constexpr int kBgSlot = kBgOutRows * kBgOut;
 constexpr int kBgLdsTab = kBgOutRows * kBgPitch;
 constexpr int kBgWaveLds = 64 * kBgTS;
 constexpr int kBgLdsWords = kBgLdsTab + kSwWaves * kBgWaveLds;
-constexpr int kBgTk = 1;                             // column blocks per flush ticket (2: measured slower, 166 k against 134 k cycles per block)
+constexpr int kBgTk = 1;                             // column blocks per flush ticket (cycles per block: 1: 116 k, 2: 118 k, 4: 144 k)
 constexpr int kBgMaxGroups = 4;                      // layer groups of this launch (its partial tiles are 64 KB each)
 
 __host__ __device__ constexpr int bgDelta(int t, int q) { return 16 * (t - kBgT0) - 4 * q; }
@@ -304,30 +304,36 @@ __global__ __launch_bounds__(64 * kSwWaves, 2) void k_superpose_sweep_big(const 
                 const bool on0 = 4 * kq <= rhoFlush, on1 = 16 + 4 * kq <= rhoFlush;
                 // (four predicated regions per step — the reads of the two row tiles, then their writes: with the predicate inside the
                 //  per-register loops the compiler made a branch around every pair of accesses)
-                static_assert(kBgTk == 1, "one column block per ticket");
-                const int t = tg;
-                float oP0[4], oM0[4], oP1[4], oM1[4];
+                float oP0[kBgTk][4], oM0[kBgTk][4], oP1[kBgTk][4], oM1[kBgTk][4];
                 if (on0) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { oP0[r] = outP[r * kBgPitch]; oM0[r] = outM[(3 - r) * kBgPitch]; }
+                    for (int u = 0; u < kBgTk; ++u)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { oP0[u][r] = outP[r * kBgPitch + 16 * u]; oM0[u][r] = outM[(3 - r) * kBgPitch + 16 * u]; }
                 }
                 if (on1) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { oP1[r] = outP[(16 + r) * kBgPitch]; oM1[r] = outM[(3 - r - 16) * kBgPitch]; }
+                    for (int u = 0; u < kBgTk; ++u)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { oP1[u][r] = outP[(16 + r) * kBgPitch + 16 * u]; oM1[u][r] = outM[(3 - r - 16) * kBgPitch + 16 * u]; }
                 }
                 if (on0) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        outP[r * kBgPitch] = oP0[r] + acc0[t][r];
-                        if (r > 0 || kq > 0) outM[(3 - r) * kBgPitch] = oM0[r] + acc0[t][r];
-                    }
+                    for (int u = 0; u < kBgTk; ++u)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            outP[r * kBgPitch + 16 * u] = oP0[u][r] + acc0[kBgTk * tg + u][r];
+                            if (r > 0 || kq > 0) outM[(3 - r) * kBgPitch + 16 * u] = oM0[u][r] + acc0[kBgTk * tg + u][r];
+                        }
                 }
                 if (on1) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        outP[(16 + r) * kBgPitch] = oP1[r] + acc1[t][r];
-                        outM[(3 - r - 16) * kBgPitch] = oM1[r] + acc1[t][r];
-                    }
+                    for (int u = 0; u < kBgTk; ++u)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            outP[(16 + r) * kBgPitch + 16 * u] = oP1[u][r] + acc1[kBgTk * tg + u][r];
+                            outM[(3 - r - 16) * kBgPitch + 16 * u] = oM1[u][r] + acc1[kBgTk * tg + u][r];
+                        }
                 }
                 if (rhoFlush == kBgR) {
 #pragma unroll
