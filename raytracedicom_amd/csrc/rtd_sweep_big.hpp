@@ -245,7 +245,7 @@ __global__ __launch_bounds__(64 * kSwWaves, 2) void k_superpose_sweep_big(const 
         float tR[2] = {0.0f, 0.0f};
 #pragma unroll
         for (int t = 0; t < kBgNCB; ++t) { acc0[t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; acc1[t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; }
-        int rhoFlush = -1;
+        int rhoFlush = -1, qmRow = 0;
         while (cur.ri == ri) {
             float dose = doseN;
             const float rs = rsN;
@@ -264,6 +264,7 @@ __global__ __launch_bounds__(64 * kSwWaves, 2) void k_superpose_sweep_big(const 
             swBuild(tab + lane * kBgTS, rs, __builtin_amdgcn_sqrtf(dose), rhoS, rhoRow, prevRho);
             prevRho = rhoRow;
             rhoFlush = max(rhoFlush, rhoRow);
+            qmRow |= qm;
             const long long db1 = dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
             // per run of four quads (16 sources): only the runs that hold a source of this launch at all — the others' tables are zeros
             // (a classification tile is 32 sources wide, and often one of a row's two is this launch's)
@@ -293,11 +294,21 @@ __global__ __launch_bounds__(64 * kSwWaves, 2) void k_superpose_sweep_big(const 
         //      one LDS round trip per step instead of two — measured slower, 199 k against 134 k: a row then holds block t until it has
         //      block t + 1's ticket, and the rows move in a convoy.) ----
         const long long df0 = dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        // column blocks the row's sources can reach: run i of four quads (sources 16 i ...) -> tile columns [16 i + 32 - rho, 16 i + 47 + rho];
+        // the others only pass their ticket on
+        int blockMask = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (qmRow & (1 << i)) {
+                const int lo = max((16 * i + 32 - rhoFlush) >> 4, 0), hi = min((16 * i + 47 + rhoFlush) >> 4, kBgNCB - 1);
+                blockMask |= ((2 << hi) - 1) & ~((1 << lo) - 1);
+            }
+        if (rhoFlush == kBgR) blockMask = (1 << kBgNCB) - 1;         // (the row |dy| = 32 is added to every block)
 #pragma unroll
         for (int tg = 0; tg < kBgNCB / kBgTk; ++tg) {
             while (__hip_atomic_load(&sTicket[tg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != ri) __builtin_amdgcn_s_sleep(1);
             __builtin_amdgcn_s_setprio(3);                           // the flush is the block's serial chain: its instructions go first
-            if (rhoFlush >= 0) {
+            if (rhoFlush >= 0 && ((blockMask >> (kBgTk * tg)) & ((1 << kBgTk) - 1)) != 0) {
                 // T[|dy| = dyBase + 4 kq + r][column 16 t + li] -> rows (ri + 32) +- |dy| of the tile; the minus side skips dy = 0
                 float* outP = sOut + (ri + kBgR + 4 * kq) * kBgPitch + 16 * kBgTk * tg + li;
                 float* outM = sOut + (ri + kBgR - 4 * kq - 3) * kBgPitch + 16 * kBgTk * tg + li;
