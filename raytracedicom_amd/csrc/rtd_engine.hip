@@ -582,6 +582,7 @@ static int createField(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dim
     {
         const float across = std::fabs(f->tracer.coefIdxI.x), along = std::fabs(f->tracer.coefOffset.x * f->tracer.delta.z);
         f->traceMode = along > kTraceAlongRatio * across ? 1 : 0;
+        if (const char* v = std::getenv("RTD_TRACE_MODE")) f->traceMode = std::atoi(v);   // diagnostics: force the plain (0) / along-beam (1) sampling kernel
     }
     f->fillGeom = makeFillGeom(h->rrlScale, rayIdxToImIdx);                                                    // :925
     f->rayIdxToDoseIdx = rayIdxToImIdx; f->rayIdxToDoseIdx.gtii = toAffine(b->gantry_to_dose_idx);             // :1185
