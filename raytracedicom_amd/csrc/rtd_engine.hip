@@ -37,7 +37,7 @@ thread_local std::string g_globalError;
 // axis carry a fixed cost (LDS transposition, longer position prefix), so they take over only once the memory axis moves this
 // much faster along their direction than along the plain one. Measured crossovers on the 512^3 field: tracer ~35 degrees
 // (0.130 vs 0.135 ms at 30, 0.166 vs 0.128 at 45), transfer ~38 degrees (0.112 vs 0.125 at 30, 0.142 vs 0.130 at 45).
-constexpr float kTraceAlongRatio = 0.7f, kTransferAxisRatio = 0.8f;
+constexpr float kTransferAxisRatio = 0.8f;
 
 struct rtd_field_impl;
 
@@ -53,6 +53,7 @@ struct rtd_handle_impl {
     size_t traceTLds = 0;         // dynamic-LDS cap set for k_trace_sample_t so far
     size_t uni3Lds = 0;           // ... for k_superpose_uniform3
     bool sweepLdsSet = false;     // ... for k_superpose_sweep
+    size_t traceDLds = 0;         // ... for k_trace_sample_d
     bool sweepBigLdsSet = false;  // ... for k_superpose_sweep_big
     unsigned inputEpoch = 0;      // bumped whenever CT, LUTs or options change (fields re-test what they learned about their input)
     // LUTs
@@ -92,7 +93,8 @@ struct rtd_field_impl {
     FillGeom fillGeom{};
     FromFan rayIdxToDoseIdx{};
     TransferParams transfer0{};
-    int traceMode = 0;              // tracer: 0 lanes across the rays, 1 along the beam (CT x runs along it)
+    int traceMode = 0;              // tracer: 0 lanes across the rays, 1 along the beam (CT x runs along it), 2 along diagonals of (ray, step) (oblique beams)
+    int traceDiagB = 0;             // ... mode 2: steps per ray along a diagonal
     int transferMode = 0;           // transfer kernel: lanes of the BEV gathers along dose x (0), y (1) or z (2)
     uint32_t doseDims[3] = {0, 0, 0};
     size_t R = 0;
@@ -580,9 +582,31 @@ static int createField(rtd_handle hh, const rtd_beam* b, const uint32_t dose_dim
     rayIdxToImIdx.dist.x = b->source_dist[0]; rayIdxToImIdx.dist.y = b->source_dist[1];                        // :657
     f->tracer = makeTracerParams(h->densityScale, h->spScale, (unsigned int)S, rayIdxToImIdx);                 // :766
     {
-        const float across = std::fabs(f->tracer.coefIdxI.x), along = std::fabs(f->tracer.coefOffset.x * f->tracer.delta.z);
-        f->traceMode = along > kTraceAlongRatio * across ? 1 : 0;
-        if (const char* v = std::getenv("RTD_TRACE_MODE")) f->traceMode = std::atoi(v);   // diagnostics: force the plain (0) / along-beam (1) sampling kernel
+        // Three sampling kernels, by the lanes' direction: across the rays (k_trace_sample), along the beam (k_trace_sample_t), along
+        // the diagonal (ray + j, step + b j) of the (ray, step) plane whose samples stay closest to one CT slice (k_trace_sample_d).
+        // What decides is the drift across CT slices (and, weakly, rows) per lane — rays: coefIdxI.z, steps: coefOffset.z * delta.z,
+        // a diagonal: their sum with b — with the kernels' measured costs on the 512^3 bench field (us, tracer stage):
+        //   across  57 + 65 drift   (0 deg 57, 20 deg 97, 30 deg 123, 45 deg 149)
+        //   along   91 + 22 drift   (90 deg 91, 75 deg 105, 60 deg 116, 45 deg 121)
+        //   diagonal 79 + 11 drift  (45 deg 79, 30 deg 88, 20 deg 94, 0 deg 101; 60 deg 87, 80 deg 97)
+        {
+            const float rayZ = f->tracer.coefIdxI.z, stepZ = f->tracer.coefOffset.z * f->tracer.delta.z;
+            const float rayY = f->tracer.coefIdxI.y, stepY = f->tracer.coefOffset.y * f->tracer.delta.z;
+            auto drift = [&](float rz, float ry) { return std::fabs(rz) + 0.05f * std::fabs(ry); };
+            int bestB = 0; float bestD = 1e30f;
+            for (int bb = -3; bb <= 3; ++bb) {
+                if (bb == 0) continue;
+                const float d = drift(rayZ + bb * stepZ, rayY + bb * stepY);
+                if (d < bestD) { bestD = d; bestB = bb; }
+            }
+            f->traceDiagB = bestB;
+            const float costAcross = 57.0f + 65.0f * drift(rayZ, rayY), costAlong = 91.0f + 22.0f * drift(stepZ, stepY);
+            const float costDiag = (W % kTdRays == 0) ? 79.0f + 11.0f * bestD : 1e30f;
+            f->traceMode = costAcross <= costAlong && costAcross <= costDiag ? 0 : (costAlong <= costDiag ? 1 : 2);
+        }
+        if (const char* v = std::getenv("RTD_TRACE_MODE")) f->traceMode = std::atoi(v);   // diagnostics: force the plain (0) / along-beam (1) / diagonal (2) sampling kernel
+        if (const char* v = std::getenv("RTD_TRACE_DIAG_B")) f->traceDiagB = std::atoi(v);
+        if (f->traceMode == 2 && (f->traceDiagB == 0 || W % kTdRays != 0)) f->traceMode = 0;
     }
     f->fillGeom = makeFillGeom(h->rrlScale, rayIdxToImIdx);                                                    // :925
     f->rayIdxToDoseIdx = rayIdxToImIdx; f->rayIdxToDoseIdx.gtii = toAffine(b->gantry_to_dose_idx);             // :1185
@@ -826,7 +850,16 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
     const size_t lutLds = (size_t)(h->lut.nDensity + h->lut.nSp) * sizeof(float);
     // dIdd doubles as the HU scratch of the tracer (it is written by k_fill only afterwards)
     const size_t tLds = lutLds + (size_t)3 * kTrRays * kTrPitch * sizeof(float);
-    if (f->traceMode != 0 && tLds <= 144 * 1024) {
+    const size_t dLds = lutLds + (size_t)3 * kTdSteps * kTdPitch * sizeof(float);
+    if (f->traceMode == 2 && dLds <= 150 * 1024) {
+        if (h->traceDLds < dLds) {
+            RTD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_trace_sample_d), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dLds));
+            h->traceDLds = dLds;
+        }
+        launchK(k_trace_sample_d, dim3((unsigned)(fc.W / kTdRays), (unsigned)fc.H, (unsigned)((fc.S + kTdSteps - 1) / kTdSteps)), dim3(kTdThreads), dLds, s, f->ev[0], nullptr,
+                (const float*)h->dCt, (int)h->ctDims[0], (int)h->ctDims[1], (int)h->ctDims[2], h->lut, f->tracer, fc.W, fc.H, f->dDensity, f->dWepl, f->dIdd,
+                f->dRrl, h->rrlScale, f->dState, (const float*)f->dSegPos, f->traceDiagB);
+    } else if (f->traceMode == 1 && tLds <= 144 * 1024) {
         // the beam runs along the CT x axis: lanes on consecutive steps of one ray (see k_trace_sample_t); 16 rays per block
         // measured best (4 .. 12 rays: 0.107 - 0.133 ms for the stage, 16: 0.100 ms)
         if (h->traceTLds < tLds) {

@@ -394,6 +394,72 @@ __global__ __launch_bounds__(64 * kTrRays) void k_trace_sample_t(const float* __
     }
 }
 
+// k_trace_sample for OBLIQUE beams (gantry 35 - 65 degrees about the CT y axis, and their mirror images): there neither lane direction
+// of the two kernels above is coherent — 64 rays in x, or 64 steps of one ray, both cross a CT slice per lane or nearly (0.12 - 0.15 ms
+// at 45 degrees against 0.057 at 0). But the samples (ray x + j, step k + b j), j = 0, 1, ..., for the right small integer b, lie
+// along CT x within ONE slice and row (at 45 degrees, b = 1: exactly): a run of 32 lanes touches a handful of cache lines per corner
+// instead of 32. A block is a region of 32 rays (one ray row) x 128 steps; its 4096 samples are taken along those diagonals (ray j,
+// step (d + b j) mod 128 for diagonal d), cross an LDS tile [step][ray] and leave step-major with lanes along the rays, like
+// k_trace_sample_t. The host picks b (-3 .. 3) that minimises the drift across slices per lane, from the field's geometry, and this
+// kernel when that drift is well below both other kernels'. Positions: k_trace_segpos's table + at most kTraceSeg - 1 additions.
+constexpr int kTdRays = 32, kTdSteps = 128, kTdPitch = 34, kTdThreads = 1024;   // (pitch 34: the diagonal writes fall into different banks for odd and even b)
+__global__ __launch_bounds__(kTdThreads) void k_trace_sample_d(const float* __restrict__ ct, int nx, int ny, int nz, LutView lut,
+                                                               TracerParams tp, int W, int H, float* __restrict__ bevDensity,
+                                                               float* __restrict__ spTerm, float* __restrict__ huBuf,
+                                                               float* __restrict__ bevRrl, float rRlScale, FieldState* st,
+                                                               const float* __restrict__ segPos, int diagB) {
+    extern __shared__ float sLut[];
+    float* sDensity = sLut;
+    float* sSp = sLut + lut.nDensity;
+    const int nLut = lut.nDensity + lut.nSp;
+    float* tile = sLut + nLut;                                       // [hu, density, sp][kTdSteps][kTdPitch]
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) resetFieldScalars(st);
+    const int x0 = blockIdx.x * kTdRays, y = blockIdx.y;
+    const unsigned int k0 = blockIdx.z * kTdSteps;
+    const size_t memStep = (size_t)W * H;
+    for (int i = tid; i < nLut; i += kTdThreads) sLut[i] = i < lut.nDensity ? lut.density[i] : lut.sp[i - lut.nDensity];
+    __syncthreads();
+    constexpr int plane = kTdSteps * kTdPitch;
+#pragma unroll
+    for (int u = 0; u < kTdRays * kTdSteps / kTdThreads; ++u) {
+        const int s = tid + u * kTdThreads;
+        const int j = s % kTdRays, d = s / kTdRays;
+        const int row = (((d + diagB * j) % kTdSteps) + kTdSteps) % kTdSteps;      // step of the region
+        const unsigned int k = k0 + row;
+        const int x = x0 + j;
+        if (k < tp.steps) {
+            const int ray = y * W + x;
+            const unsigned int seg = k / kTraceSeg, r = k - seg * kTraceSeg;
+            const float* q = segPos + (size_t)seg * 3 * memStep + ray;
+            Vec3 pos = v3(q[0], q[memStep], q[2 * memStep]);
+            const Vec3 step = tp.getInc(x, y);
+            for (unsigned int i = 0; i < r; ++i) pos = pos + step;   // same float sequence as the serial walk
+            const float huPlus1000 = sample3dBorder(ct, nx, ny, nz, pos.x, pos.y, pos.z);
+            float* t = tile + row * kTdPitch + j;
+            t[0] = huPlus1000;
+            t[plane] = sample1dClamp(sDensity, lut.nDensity, huPlus1000 * tp.densityScale);
+            t[2 * plane] = tp.stepLen(x, y) * sample1dClamp(sSp, lut.nSp, huPlus1000 * tp.spScale);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kTdRays * kTdSteps / kTdThreads; ++u) {
+        const int s = tid + u * kTdThreads;
+        const int j = s % kTdRays, row = s / kTdRays;
+        const unsigned int k = k0 + row;
+        if (k < tp.steps) {
+            const size_t idx = (size_t)k * memStep + (size_t)y * W + x0 + j;
+            const float* t = tile + row * kTdPitch + j;
+            huBuf[idx] = t[0];
+            const float density = t[plane];
+            bevDensity[idx] = density;
+            spTerm[idx] = t[2 * plane];
+            bevRrl[idx] = density * sample1dClamp(lut.rrl, lut.nRrl, density * rRlScale);   // (see k_trace_sample)
+        }
+    }
+}
+
 // The sums are serial per ray (float order of the reference walk, kernel_wrapper.cu:147-186), so only R/64 serial
 // chains of 64 lanes exist: a plain one-wave-per-64-rays walk keeps ~2 MB of loads in flight and is bound by memory
 // latency (measured 57 us for 51 MB). Here a block of kScanWaves waves serves 64 rays: ALL waves stream the next chunk of
