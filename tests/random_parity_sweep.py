@@ -1,5 +1,5 @@
 """Random parity sweep on a GPU box (not collected by pytest): seeded random scenarios through tests/test_gpu_parity._compare_field,
-every intermediate and the dose against the CPU oracle. Usage: python tests/random_parity_sweep.py FIRST_SEED END_SEED.
+every intermediate and the dose against the CPU oracle. Usage: python tests/random_parity_sweep.py FIRST_SEED END_SEED [rays | angles].
 Ray weights and every integer are compared bit for bit; dose deviations confined to the tail are reported and the sweep goes on;
 anything else raises."""
 import os, sys, math
@@ -25,6 +25,8 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     # (drawn last, so the scenarios of the earlier sweeps keep their seeds) a quarter of the scenarios with finer rays: batch radii
     # beyond 16 pixels, the second sweep launch
     rs = float(rng.choice([1.0, 1.0, 1.0, 0.75, 0.6])) if len(sys.argv) > 3 and sys.argv[3] == "rays" else 1.0
+    if len(sys.argv) > 3 and sys.argv[3] == "angles":      # any gantry angle (the host's choice among the three sampling kernels, the transfers' lane axes)
+        deg = float(rng.uniform(0.0, 360.0))
     if rs != 1.0:
         spots = min(spots, 6)
     scn = scenarios.hetero_ct(synth, n=n, spots=spots, pitch=pitch, n_layers=n_layers, angles=[deg], source_dist=dist, steps=steps, ct=ct,
