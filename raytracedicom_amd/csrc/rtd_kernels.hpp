@@ -494,14 +494,20 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_trace_scan(const float* __r
             rSp[j] = i < steps ? bevCumulSp[ray + (size_t)i * memStep] : 0.0f;   // holds stepLen*SP(hu) from k_trace_sample
         }
     };
-    auto stage = [&](int buf) {
+    // Only the two running sums are serial. The two index searches of the reference walk — the last step whose running HU sum is below
+    // 150 (:173-176), the last step whose HU is above 150 (:177-180) — are maxima over steps: every wave takes them over ITS steps (the
+    // raw HU values as it stages them, the running sums once wave 1 has written them back), and the waves' partial maxima meet at the end.
+    int beforeFirstInside = -1, lastInside = -1;                     // this wave's partial maxima (lane = ray)
+    auto stage = [&](int buf, unsigned int cBase) {
 #pragma unroll
-        for (int j = 0; j < kScanPerWave; ++j) { sHu(buf, wv * kScanPerWave + j) = rHu[j]; sSp(buf, wv * kScanPerWave + j) = rSp[j]; }
+        for (int j = 0; j < kScanPerWave; ++j) {
+            sHu(buf, wv * kScanPerWave + j) = rHu[j]; sSp(buf, wv * kScanPerWave + j) = rSp[j];
+            lastInside = max(lastInside, rHu[j] > 150.0f ? (int)(cBase + wv * kScanPerWave + j) : -1);   // (zeros beyond the last step never pass)
+        }
     };
     float cumulSp = 0.0f, cumulHuPlus1000 = 0.0f;
-    int beforeFirstInside = -1, lastInside = -1;
     fetch(0);
-    stage(0);
+    stage(0, 0u);
     __syncthreads();
     stamp();
     int buf = 0;
@@ -510,6 +516,7 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_trace_scan(const float* __r
         // (steps past the end were staged as zeros: they change no sum and set no index)
         constexpr int kU = 16;                                       // LDS reads issued ahead of the serial adds
         if (wv == 0) {
+            // (requesting the next batch's LDS reads before this batch's chain of additions measured slower: 7.1 k against 6.0 k cycles per chunk)
             for (int j0 = 0; j0 < kScanChunk; j0 += kU) {
                 float v[kU];
 #pragma unroll
@@ -518,44 +525,26 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_trace_scan(const float* __r
                 for (int j = 0; j < kU; ++j) { cumulSp += v[j]; sSp(buf, j0 + j) = cumulSp; }
             }
         } else if (wv == 1) {
-            // "the last step at which the running sum is below 150" as a running maximum of the steps where it is: the sums are one
-            // chain of dependent additions, the maximum another, and neither waits for a compare-and-branch per step (the first form
-            // of this loop: 63 cycles per step, 56 % of the kernel — clock stamps, tools/scan_dbg.py)
-            const int nJ = (int)min((unsigned int)kScanChunk, steps - c0);          // steps of this chunk (the rest was staged as zeros)
-            for (int j0 = 0; j0 < nJ; j0 += kU) {
-                float v[kU];
-#pragma unroll
-                for (int j = 0; j < kU; ++j) v[j] = sHu(buf, j0 + j);
-#pragma unroll
-                for (int j = 0; j < kU; ++j) { cumulHuPlus1000 += v[j]; v[j] = cumulHuPlus1000; }
-                const int i0 = (int)c0 + j0;
-                if (j0 + kU <= nJ) {                                 // (wave-uniform)
-#pragma unroll
-                    for (int j = 0; j < kU; ++j) beforeFirstInside = max(beforeFirstInside, v[j] < 150.0f ? i0 + j : -1);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < kU; ++j) beforeFirstInside = max(beforeFirstInside, (v[j] < 150.0f && j0 + j < nJ) ? i0 + j : -1);
-                }
-            }
-        } else if (wv == 2) {
+            // (until round 3 this wave also compared every sum with 150 and a third wave searched the raw values: 63 cycles per step,
+            //  56 % of the kernel — clock stamps, tools/scan_dbg.py)
             for (int j0 = 0; j0 < kScanChunk; j0 += kU) {
                 float v[kU];
 #pragma unroll
                 for (int j = 0; j < kU; ++j) v[j] = sHu(buf, j0 + j);
-                const int i0 = (int)c0 + j0;                         // (zeros beyond the last step never pass the test)
 #pragma unroll
-                for (int j = 0; j < kU; ++j) lastInside = max(lastInside, v[j] > 150.0f ? i0 + j : -1);
+                for (int j = 0; j < kU; ++j) { cumulHuPlus1000 += v[j]; sHu(buf, j0 + j) = cumulHuPlus1000; }
             }
         }
         ldsBarrier();                                                // chunk walked
         stamp();
-        float wOut[kScanPerWave];                                    // (all LDS reads first: one round trip, not one per step)
+        float wOut[kScanPerWave], hOut[kScanPerWave];                // (all LDS reads first: one round trip, not one per step)
 #pragma unroll
-        for (int j = 0; j < kScanPerWave; ++j) wOut[j] = sSp(buf, wv * kScanPerWave + j);
+        for (int j = 0; j < kScanPerWave; ++j) { wOut[j] = sSp(buf, wv * kScanPerWave + j); hOut[j] = sHu(buf, wv * kScanPerWave + j); }
 #pragma unroll
         for (int j = 0; j < kScanPerWave; ++j) {                     // all waves store the chunk's WEPL
             const unsigned int i = c0 + wv * kScanPerWave + j;
             if (i < steps) {
+                if (hOut[j] < 150.0f) beforeFirstInside = max(beforeFirstInside, (int)i);
                 const float wepl = wOut[j];
                 bevCumulSp[ray + (size_t)i * memStep] = wepl;
                 // sliceMinVar<float> (kernel_wrapper.cuh:215-244, launch kernel_wrapper.cu:788), first level: this block's 64 rays;
@@ -567,18 +556,30 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_trace_scan(const float* __r
         stamp();
         if (c0 + kScanChunk < steps) {
             ldsBarrier();                                            // chunk stored: the buffer takes the next one
-            stage(buf);
+            stage(buf, c0 + kScanChunk);
             ldsBarrier();
             stamp();
         }
     }
+    // the waves' partial maxima meet: [wave][ray] in the (now free) chunk buffer
+    ldsBarrier();
+    int* sPart = reinterpret_cast<int*>(sScan);
+    sPart[wv * 64 + lane] = beforeFirstInside;
+    sPart[(kScanWaves + wv) * 64 + lane] = lastInside;
+    ldsBarrier();
     if (wv == 1) {
-        firstInside[ray] = beforeFirstInside + 1;
-        const int mn = waveMinI(beforeFirstInside + 1);
+        int v = -1;
+#pragma unroll
+        for (int w = 0; w < kScanWaves; ++w) v = max(v, sPart[w * 64 + lane]);
+        firstInside[ray] = v + 1;
+        const int mn = waveMinI(v + 1);
         if (lane == 0) atomicMin(&st->beamFirstInside, mn);
     } else if (wv == 2) {
-        firstOutside[ray] = lastInside + 1;
-        const int mx = waveMaxI(lastInside + 1);
+        int v = -1;
+#pragma unroll
+        for (int w = 0; w < kScanWaves; ++w) v = max(v, sPart[(kScanWaves + w) * 64 + lane]);
+        firstOutside[ray] = v + 1;
+        const int mx = waveMaxI(v + 1);
         if (lane == 0) atomicMax(&st->beamFirstOutside, mx);
     }
 }
