@@ -1,6 +1,7 @@
 """Clock stamps of k_superpose_sweep's blocks on the bench field (RTD_SWEEP_DEBUG=1)."""
 import os, sys
 os.environ["RTD_SWEEP_DEBUG"] = "1"
+os.environ["RTD_SEPARATE_KS_PLAN"] = "1"      # (the stamps are indexed by the blocks of the launch without the plan block in front)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
