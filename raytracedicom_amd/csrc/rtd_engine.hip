@@ -51,6 +51,7 @@ struct rtd_handle_impl {
     int numCUs = 256;             // compute units of the device (grid size of the grid-stride kernels)
     bool scanLdsSet = false;      // dynamic-LDS cap of k_trace_scan raised (once per handle)
     size_t traceTLds = 0;         // dynamic-LDS cap set for k_trace_sample_t so far
+    bool uni4LdsSet = false;      // ... for k_superpose_uniform4
     size_t uni3Lds = 0;           // ... for k_superpose_uniform3
     bool sweepLdsSet = false;     // ... for k_superpose_sweep
     size_t traceDLds = 0;         // ... for k_trace_sample_d
@@ -126,6 +127,7 @@ struct rtd_field_impl {
     TransferParams transfer0Nuc{};
     int transferModeNuc = 0;
     long long* dFillDbg = nullptr; size_t fillDbgN = 0;   // RTD_FILL_DEBUG: per-block clock stamps of k_fill (diagnostics)
+    long long* dUniDbg = nullptr; size_t uniDbgN = 0;     // RTD_UNIFORM_DEBUG: per-block clock stamps of k_superpose_uniform4 (diagnostics)
     long long* dSweepDbg = nullptr; size_t sweepDbgN = 0; // RTD_SWEEP_DEBUG: per-block clock stamps of k_superpose_sweep (diagnostics)
     long long* dSweepBigDbg = nullptr; size_t sweepBigDbgN = 0; // ... and of k_superpose_sweep_big
     long long* dScanDbg = nullptr; size_t scanDbgN = 0;         // RTD_SCAN_DEBUG: ... of k_trace_scan
@@ -494,7 +496,7 @@ int rtd_field_destroy(rtd_handle hh, rtd_field ff) {
     (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = { f->dSpotWeights, f->dConvInterm, f->dRayWeights, f->dDensity, f->dWepl, f->dRrl, f->dIdd, f->dRSigma, f->dBev, f->dBevPart, f->dNodeCount, f->dSwSlots, f->dSwCount, f->dSwSlotsBig, f->dSwCountBig,
                      f->dFirstInside, f->dFirstOutside, f->dFirstPassive, f->dWeplMin, f->dBlockWeplMin, f->dSegPos, f->dKsArgs, f->dTileRad,
-                     f->dLayers, f->dState, f->dStepTab, f->dActive, f->dSigMin, f->dSigMax, f->dFillDbg, f->dSweepDbg, f->dSweepBigDbg, f->dScanDbg,
+                     f->dLayers, f->dState, f->dStepTab, f->dActive, f->dSigMin, f->dSigMax, f->dFillDbg, f->dSweepDbg, f->dSweepBigDbg, f->dScanDbg, f->dUniDbg,
                      f->dNucSpotIdx, f->dNucRayWeights, f->dNucIdd, f->dNucRs, f->dNucBev, f->dNucEffT, f->dStateNuc };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (f->hState) (void)hipHostFree(f->hState);
@@ -952,7 +954,24 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
         const size_t u3Lds = (size_t)2 * fc.H * (fc.W + 16) * sizeof(float);
         const bool u3 = fc.W <= 16 * (kU2XB - 4) && nYB <= 16 && u3Lds <= 150 * 1024 && (size_t)fc.W * fc.H / 4 <= (size_t)kU3MaxV4 * 64 * nYB &&
                         std::getenv("RTD_UNIFORM_V2") == nullptr;
-        if (u3) {
+        const bool u4 = fc.W <= 16 * (kU2XB - 4) && fc.W % 4 == 0 && std::getenv("RTD_UNIFORM_V4") != nullptr;
+        if (u4) {
+            // (rtd_uniform.hpp: a block per three row blocks of a slice, the rows within their reach staged layer by layer)
+            const int nPartsU4 = (nYB + kU4RB - 1) / kU4RB;
+            if (!h->uni4LdsSet) {
+                RTD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_superpose_uniform4), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)((kU4Rows + kU4Slack) * (16 * (kU2XB - 4) + 16) * sizeof(float))));
+                h->uni4LdsSet = true;
+            }
+            if (!f->dUniDbg && std::getenv("RTD_UNIFORM_DEBUG")) {
+                f->uniDbgN = (size_t)16 * fc.S * nPartsU4;
+                RTD_HIP(h, hipMalloc((void**)&f->dUniDbg, f->uniDbgN * sizeof(long long)));
+                RTD_HIP(h, hipMemset(f->dUniDbg, 0, f->uniDbgN * sizeof(long long)));
+            }
+            launchK(k_superpose_uniform4, dim3((unsigned)(fc.S * nPartsU4)), dim3(64 * kU4Waves), (size_t)(kU4Rows + kU4Slack) * (fc.W + 16) * sizeof(float), s, ksStart,
+                    knownUniform ? f->ev[5] : nullptr, (const float*)f->dIdd, (const LayerPlan*)f->dLayers, (const FieldState*)f->dState, fc,
+                    (const unsigned int*)f->dSigMin, (const float*)f->dStepTab, f->dBev, f->dUniDbg);
+        } else if (u3) {
             // (rtd_uniform.hpp: one block per slice, its layers staged in two LDS buffers a layer ahead)
             if (h->uni3Lds < u3Lds) {
                 RTD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_superpose_uniform3<768>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)u3Lds));
@@ -1318,6 +1337,7 @@ int rtd_field_fetch(rtd_handle hh, rtd_field ff, const char* name, void* host_ou
     else if (nm == "tile_radius") { src = f->dTileRad; n = L * S * tiles; }
     else if (nm == "bev") { src = f->dBev; n = 4 * (size_t)fc.bevW * fc.bevH * S; }
     else if (nm == "fill_debug" && f->dFillDbg) { src = f->dFillDbg; n = f->fillDbgN * sizeof(long long); }
+    else if (nm == "uniform_debug" && f->dUniDbg) { src = f->dUniDbg; n = f->uniDbgN * sizeof(long long); }
     else if (nm == "sweep_debug" && f->dSweepDbg) { src = f->dSweepDbg; n = f->sweepDbgN * sizeof(long long); }
     else if (nm == "sweep_big_debug" && f->dSweepBigDbg) { src = f->dSweepBigDbg; n = f->sweepBigDbgN * sizeof(long long); }
     else if (nm == "scan_debug" && f->dScanDbg) { src = f->dScanDbg; n = f->scanDbgN * sizeof(long long); }

@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "librtd_hip.so")
 _LIB = None
 
 _FETCH_DTYPES = {"first_inside": np.int32, "first_outside": np.int32, "first_passive": np.int32,
-                 "eff_radius": np.int32, "tile_radius": np.uint8, "fill_debug": np.int64, "sweep_debug": np.int64, "sweep_big_debug": np.int64, "scan_debug": np.int64}
+                 "eff_radius": np.int32, "tile_radius": np.uint8, "fill_debug": np.int64, "sweep_debug": np.int64, "uniform_debug": np.int64, "sweep_big_debug": np.int64, "scan_debug": np.int64}
 
 
 class RtdError(RuntimeError):
