@@ -52,7 +52,6 @@ struct rtd_handle_impl {
     bool scanLdsSet = false;      // dynamic-LDS cap of k_trace_scan raised (once per handle)
     size_t traceTLds = 0;         // dynamic-LDS cap set for k_trace_sample_t so far
     bool uni4LdsSet = false;      // ... for k_superpose_uniform4
-    size_t uni3Lds = 0;           // ... for k_superpose_uniform3
     bool sweepLdsSet = false;     // ... for k_superpose_sweep
     size_t traceDLds = 0;         // ... for k_trace_sample_d
     bool sweepBigLdsSet = false;  // ... for k_superpose_sweep_big
@@ -951,12 +950,9 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
         // on the device only (FieldState::uniformField): the launch returns at once otherwise, k_superpose_mfma below when it is.
         // A small persistent grid, so that the empty launch of a heterogeneous field costs next to nothing.
         const int nYB = (fc.bevH + 15) / 16;
-        const size_t u3Lds = (size_t)2 * fc.H * (fc.W + 16) * sizeof(float);
-        const bool u3 = fc.W <= 16 * (kU2XB - 4) && nYB <= 16 && u3Lds <= 150 * 1024 && (size_t)fc.W * fc.H / 4 <= (size_t)kU3MaxV4 * 64 * nYB &&
-                        std::getenv("RTD_UNIFORM_V2") == nullptr;
-        const bool u4 = fc.W <= 16 * (kU2XB - 4) && fc.W % 4 == 0 && std::getenv("RTD_UNIFORM_V4") != nullptr;
+        const bool u4 = fc.W <= 16 * (kU2XB - 4) && fc.W % 4 == 0 && std::getenv("RTD_UNIFORM_V2") == nullptr;
         if (u4) {
-            // (rtd_uniform.hpp: a block per three row blocks of a slice, the rows within their reach staged layer by layer)
+            // (rtd_uniform.hpp: a block per four row blocks of a slice, the rows within their reach staged layer by layer)
             const int nPartsU4 = (nYB + kU4RB - 1) / kU4RB;
             if (!h->uni4LdsSet) {
                 RTD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_superpose_uniform4), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -971,18 +967,6 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
             launchK(k_superpose_uniform4, dim3((unsigned)(fc.S * nPartsU4)), dim3(64 * kU4Waves), (size_t)(kU4Rows + kU4Slack) * (fc.W + 16) * sizeof(float), s, ksStart,
                     knownUniform ? f->ev[5] : nullptr, (const float*)f->dIdd, (const LayerPlan*)f->dLayers, (const FieldState*)f->dState, fc,
                     (const unsigned int*)f->dSigMin, (const float*)f->dStepTab, f->dBev, f->dUniDbg);
-        } else if (u3) {
-            // (rtd_uniform.hpp: one block per slice, its layers staged in two LDS buffers a layer ahead)
-            if (h->uni3Lds < u3Lds) {
-                RTD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_superpose_uniform3<768>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)u3Lds));
-                RTD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_superpose_uniform3<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)u3Lds));
-                h->uni3Lds = u3Lds;
-            }
-            auto launchU3 = [&](auto kern) {
-                launchK(kern, dim3((unsigned)fc.S), dim3(64 * nYB), u3Lds, s, ksStart, knownUniform ? f->ev[5] : nullptr, (const float*)f->dIdd,
-                        (const LayerPlan*)f->dLayers, (const FieldState*)f->dState, fc, (const unsigned int*)f->dSigMin, (const float*)f->dStepTab, f->dBev);
-            };
-            if (nYB <= 12) launchU3(k_superpose_uniform3<768>); else launchU3(k_superpose_uniform3<1024>);
         } else {
             // (rtd_uniform.hpp: one wave per 16 rows x 192 columns of a slice, no staging, no barrier in its loop)
             const int nXS = (fc.bevW + 16 * kU2XB - 1) / (16 * kU2XB), nParts = ((fc.bevH + 15) / 16 + 3) / 4;

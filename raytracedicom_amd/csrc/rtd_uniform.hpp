@@ -16,17 +16,23 @@
 //            and the steps outside an output block's reach are skipped. No transposition, no LDS round trip. B[k = c][j = x] from the
 //            weight table again. D[i = y][j = x]: stored as 64-byte rows.
 // The weights (the same pixel integrals as the general kernels: Taylor series for sigma >= 1.4 px, erf differences below) depend on the
-// layer only: a wave looks its B operands up once per layer (12 + 20 registers), not per product. The layers of a slice are added in
+// layer only: a wave looks its B operands up once per layer, not per product. The layers of a slice are added in
 // ascending order into the same accumulators (12 column blocks): reproducible.
-//   k_superpose_uniform3  block = ONE slice, wave = one of its (<= 16) row blocks; the slice's layers staged in two LDS buffers a layer
-//                         ahead, one barrier per layer. Ray grids of up to 128 columns (the reference's water cube: 0.24 ms).
+//   k_superpose_uniform4  block = four row blocks of a slice, one per wave; the layers' rows within the block's reach staged in LDS a layer
+//                         ahead. Ray grids of up to 128 columns (the reference's water cube: 0.17 ms).
 //   k_superpose_uniform2  wave = (slice, row block, strip of 192 columns), A operands straight from global memory (the input rows are
 //                         re-read by the row blocks within reach, through L1 / L2), no barrier in the loop: any grid (0.32 ms there — a
 //                         wave waits a memory round trip per input column block).
 // History on the reference's water cube (256^3, 20 layers; the general kernel of round 2 took 1.18 ms): vector ALUs with a sliding window
 // 0.71 ms; first matrix version 0.67 ms; round 2's kernel — x pass, barrier, y pass, barrier per 32-row chunk staged in LDS, four waves
-// per block, matrix cores busy 19 % — 0.36 ms; these two 0.32 and 0.24 ms. What is left is mostly matrix work: at the cube's radii
-// (up to 16) a wave issues ~250 MFMAs per layer, two thirds of them in pass 2 (12 output column blocks against 8 input ones).
+// per block, matrix cores busy 19 % — 0.36 ms; k_superpose_uniform2 0.32 ms; a block per slice with its layers double-buffered in LDS
+// (k_superpose_uniform3, round 3, since removed) 0.24 ms: 190 of 256 CUs, and the counters showed three scalar branches per matrix
+// instruction (the reach tests) — 0.225 ms with the radius classes below; the slice cut into three blocks 0.19 ms; reads first and
+// selects after instead of predicated reads (a branch each) 0.18 ms; the next column block's values read ahead 0.17 ms. Clock stamps
+// (tools/uniform_dbg.py): of ~15 000 cycles per layer and block, ~4000 are the two barriers and the store of the next layer's rows,
+// ~5000 the issue of the thirteen loads of the layer after (the CU's eight waves queue 104 KB of requests at once), the matrix
+// instructions of a wave ~4000 (two waves per SIMD). Spreading the loads over the column blocks moved the wait into the store
+// (0.19 ms, more registers): the layer's rows arrive at ~2.4 TB/s over all CUs, twice the unique bytes (the blocks' reaches overlap).
 #pragma once
 #include "rtd_kernels.hpp"
 
@@ -210,261 +216,12 @@ __global__ __launch_bounds__(256, 2) void k_superpose_uniform2(const float* __re
     }
 }
 
-// The same two passes with the slice's layers staged in LDS: the block stages layer a + 1 (float4 loads, a layer ahead in registers,
-// then one of two LDS buffers) while layer a is on the matrix cores: ONE barrier per layer, pass 1's A operands come from LDS (pitch
-// W + 16: the four rows of a k step fall into different banks).
-constexpr int kU3MaxV4 = 6;                          // float4 a thread stages per layer (H W / 4 <= 6 x 64 x row blocks)
-template <int kMaxThreads>                           // 768: slices of up to 12 row blocks (three waves per SIMD: 168 registers); 1024: up to 16
-__global__ __launch_bounds__(kMaxThreads) void k_superpose_uniform3(const float* __restrict__ bevIdd, const LayerPlan* __restrict__ layers,
-                                                              const FieldState* __restrict__ st, FieldConst fc,
-                                                              const unsigned int* __restrict__ sigMin, const float* __restrict__ stepTab,
-                                                              float* __restrict__ bevDose) {
-    if (!st->uniformField || st->errorFlags) return;
-    extern __shared__ float sIn[];                                   // two buffers [H][W + 16]
-    __shared__ float sW[16][64];                                     // per wave: w[0 .. rho] of its current layer, zeros beyond
-    __shared__ int sLay[256], sRho[256], sCount[4];
-    __shared__ float sRs[256];
-    const int t = threadIdx.x, nT = blockDim.x;
-    const int wv = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, li = lane & 15, kq = lane >> 4;
-    const int W = fc.W, H = fc.H, S = fc.S;
-    const int first = st->beamFirstInside, passive = st->firstCalculatedPassive;
-    const int k = blockIdx.x;
-    if (k < first || k >= passive) return;
-    const size_t memStep = (size_t)W * H;
-    const int pitch = W + 16;
-    // ---- the slice's depositing layers, ascending, with their 1/sigma and batch radius (thread l looks at layer l; L <= 256 <= nT) ----
-    {
-        bool on = false; float rs = 0.0f; int rho = 0;
-        if (t < fc.L && k < layers[t].layerFirstPassive) {
-            const unsigned int bits = sigMin[(size_t)t * S + k];
-            if (bits != 0x7f800000u) {
-                const float sig2 = __uint_as_float(bits);
-                const float sqrt2 = 1.41421356f;
-                rs = stepTab[2 * k] * __builtin_amdgcn_rcpf(sqrt2 * (__builtin_amdgcn_sqrtf(sig2) + 0.21f));
-                const float minRs = stepTab[2 * k] / (sqrt2 * (sqrtf(sig2) + 0.21f));
-                int cls = f2iSat(fc.ksSigmaCutoff / (sqrtf(2.0f) * minRs) + 0.5f);
-                cls = cls > kMaxSuperpR ? kMaxSuperpR : (cls < 0 ? 0 : cls);
-                rho = layers[t].effRad[cls];
-                on = true;
-            }
-        }
-        const unsigned long long mask = __ballot(on);
-        if (lane == 0 && wv < 4) sCount[wv] = __popcll(mask);
-        __syncthreads();
-        int pos = __popcll(mask & ((1ull << lane) - 1ull));
-        for (int w2 = 0; w2 < wv && w2 < 4; ++w2) pos += sCount[w2];
-        if (on) { sLay[pos] = t; sRho[pos] = rho; sRs[pos] = rs; }
-        __syncthreads();
-    }
-    const int nA = sCount[0] + sCount[1] + sCount[2] + sCount[3];
-    const int y0 = 16 * wv;                                          // first padded-BEV row of the wave
-    const int nCB = W / 16;
-    float* sw = sW[wv];
-    const int nV4 = (int)(memStep / 4), rowV4 = W / 4;
-
-    // staging: this thread's float4 of a layer's slice -> registers (s0 .. s5) -> LDS buffer
-    float4 s0, s1, s2, s3, s4, s5;
-    s0 = s1 = s2 = s3 = s4 = s5 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    static_assert(kU3MaxV4 == 6, "six staging registers");
-#define RTD_U3_FETCH(a_)                                                                                                     \
-    {                                                                                                                        \
-        const float4* __restrict__ src = reinterpret_cast<const float4*>(bevIdd + ((size_t)sLay[a_] * S + k) * memStep);     \
-        if (t < nV4) s0 = src[t];                                                                                            \
-        if (t + nT < nV4) s1 = src[t + nT];                                                                                  \
-        if (t + 2 * nT < nV4) s2 = src[t + 2 * nT];                                                                          \
-        if (t + 3 * nT < nV4) s3 = src[t + 3 * nT];                                                                          \
-        if (t + 4 * nT < nV4) s4 = src[t + 4 * nT];                                                                          \
-        if (t + 5 * nT < nV4) s5 = src[t + 5 * nT];                                                                          \
-    }
-    auto put = [&](float* dst, int i, const float4& v) {
-        if (i < nV4) {
-            const int r = i / rowV4, c = 4 * (i - r * rowV4);
-            *reinterpret_cast<float4*>(dst + (size_t)r * pitch + c) = v;
-        }
-    };
-#define RTD_U3_STORE(buf_)                                                                                                   \
-    {                                                                                                                        \
-        float* dst = sIn + (size_t)(buf_) * H * pitch;                                                                       \
-        put(dst, t, s0); put(dst, t + nT, s1); put(dst, t + 2 * nT, s2); put(dst, t + 3 * nT, s3); put(dst, t + 4 * nT, s4); put(dst, t + 5 * nT, s5); \
-    }
-
-    f32x4 acc[kU2XB];
-#pragma unroll
-    for (int q = 0; q < kU2XB; ++q) acc[q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-
-    if (nA > 0) { RTD_U3_FETCH(0); RTD_U3_STORE(0); }
-    __syncthreads();
-    if (nA > 1) RTD_U3_FETCH(1);
-    for (int a = 0; a < nA; ++a) {
-        const int rho = sRho[a];
-        const float rs = sRs[a];
-        const float* __restrict__ in = sIn + (size_t)(a & 1) * H * pitch;
-        const int rLo = max(0, y0 - 32 - rho) & ~3, rHi = min(H - 1, y0 - 17 + rho);
-        if (rHi >= rLo) {                                            // (wave-uniform; a wave out of the layer's reach only keeps the barriers)
-            const int nK = (rHi - rLo) / 4 + 1;                      // <= 21
-            {
-                float w = 0.0f;
-                if (lane <= rho) {
-                    const int ii = lane;
-                    if (rs <= 0.5f) {
-                        const float h2 = rs * rs, h4 = h2 * h2;
-                        const float k1 = h2 * (1.0f / 24.0f), k2 = h4 * (1.0f / 1920.0f), k3 = h4 * h2 * (1.0f / 322560.0f);
-                        const float c0 = 1.0f - 2.0f * k1 + 12.0f * k2 - 120.0f * k3;
-                        const float c1 = (4.0f * k1 - 48.0f * k2 + 720.0f * k3) * h2;
-                        const float c2 = (16.0f * k2 - 480.0f * k3) * h4;
-                        const float c3 = 64.0f * k3 * (h4 * h2);
-                        const float wq = (float)(ii * ii);
-                        const float gq = 0.5641895835f * rs * __builtin_amdgcn_exp2f(-1.4426950409f * h2 * wq);
-                        w = gq * __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(c3, wq, c2), wq, c1), wq, c0);
-                    } else {
-                        w = ii == 0 ? erff(rs * 0.5f) : 0.5f * (erff(rs * ((float)ii + 0.5f)) - erff(rs * ((float)ii - 0.5f)));
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-                sw[lane] = w;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
-            const int d1 = rLo + kq - (y0 + li - 32);
-            const int rHi4 = min(H - 1, rLo + 4 * nK - 1);           // (the generic form's rows: s1 < nK and r < H)
-            // A radius class R (rho <= R <= 16) fixes the pattern of the layer's matrix instructions: (18 + 2 R) / 4 + 1 k steps per column
-            // block in pass 1, the k steps 29 - R <= 16 jj + 4 s2 <= 47 + R in pass 2 — no branch per instruction (the counters showed
-            // three scalar branches and nine scalar instructions per matrix instruction in the generic form below, the matrix pipe 20 % busy);
-            // the k steps beyond the layer's own reach multiply zero weights.
-            auto layerStatic = [&](auto rTag) {
-                constexpr int R = decltype(rTag)::value, NK = (18 + 2 * R) / 4 + 1;
-                float b1[NK], b2[kU2Reach][4];
-#pragma unroll
-                for (int s = 0; s < NK; ++s) {
-                    const int d = d1 + 4 * s;
-                    b1[s] = sw[min(d < 0 ? -d : d, kU2Guard)];
-                }
-                const int d2 = kq - li - 32;
-#pragma unroll
-                for (int jj = 0; jj < kU2Reach; ++jj)
-#pragma unroll
-                    for (int s2 = 0; s2 < 4; ++s2) {
-                        const int d = d2 + 16 * jj + 4 * s2;
-                        if (16 * jj + 4 * s2 >= 29 - R && 16 * jj + 4 * s2 <= 47 + R) b2[jj][s2] = sw[min(d < 0 ? -d : d, kU2Guard)];
-                    }
-                const float* col0 = in + (rLo + kq) * pitch + 4 * (li & 3) + (li >> 2);
-#pragma unroll
-                for (int j = kU2Reach - 1; j < kU2CB; ++j) {
-                    const int cb = j - (kU2Reach - 1);
-                    if (cb >= nCB) break;                            // (wave-uniform)
-                    f32x4 tmp = {0.0f, 0.0f, 0.0f, 0.0f};
-                    const float* col = col0 + 16 * cb;
-                    float av[NK];
-#pragma unroll
-                    for (int s1 = 0; s1 < NK; ++s1) av[s1] = (rLo + 4 * s1 + kq <= rHi4) ? col[4 * s1 * pitch] : 0.0f;
-#pragma unroll
-                    for (int s1 = 0; s1 < NK; ++s1) tmp = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s1], b1[s1], tmp, 0, 0, 0);
-#pragma unroll
-                    for (int jj = 0; jj < kU2Reach; ++jj) {
-                        const int q = j - jj;                        // (static)
-                        if (q < 0 || q >= kU2XB) continue;
-#pragma unroll
-                        for (int s2 = 0; s2 < 4; ++s2)
-                            if (16 * jj + 4 * s2 >= 29 - R && 16 * jj + 4 * s2 <= 47 + R)      // (static)
-                                acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(tmp[s2], b2[jj][s2], acc[q], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);               // (the loads of the next column block stay behind: registers)
-                }
-            };
-            if (rho <= 4) layerStatic(std::integral_constant<int, 4>{});
-            else if (rho <= 8) layerStatic(std::integral_constant<int, 8>{});
-            else if (rho <= 12) layerStatic(std::integral_constant<int, 12>{});
-            else if (rho <= 16) layerStatic(std::integral_constant<int, 16>{});
-            else {
-            float b1[kU2Run], b2[kU2Reach][4];                       // (the k steps beyond kU2Run look their weights up on the spot)
-            {
-#pragma unroll
-                for (int s = 0; s < kU2Run; ++s) {
-                    const int d = d1 + 4 * s;
-                    b1[s] = s < nK ? sw[min(d < 0 ? -d : d, kU2Guard)] : 0.0f;
-                }
-                const int d2 = kq - li - 32;
-#pragma unroll
-                for (int jj = 0; jj < kU2Reach; ++jj)
-#pragma unroll
-                    for (int s2 = 0; s2 < 4; ++s2) {
-                        const int d = d2 + 16 * jj + 4 * s2;
-                        b2[jj][s2] = sw[min(d < 0 ? -d : d, kU2Guard)];
-                    }
-            }
-#pragma unroll
-            for (int j = 0; j < kU2CB; ++j) {
-                const int cb = j - (kU2Reach - 1);                   // (one strip: x0 = 0)
-                const bool need = cb >= 0 && cb < nCB && 16 * cb + 15 >= -32 - rho && 16 * cb <= 16 * kU2XB - 17 + rho;
-                if (!need) continue;                                 // (wave-uniform)
-                f32x4 tmp = {0.0f, 0.0f, 0.0f, 0.0f};
-                const float* col = in + 16 * cb + 4 * (li & 3) + (li >> 2);   // row i of A <-> column 4 (i % 4) + i / 4 of the block (see pass 2)
-                {
-                    float av[kU2Run];
-#pragma unroll
-                    for (int s1 = 0; s1 < kU2Run; ++s1) {
-                        const int r = rLo + 4 * s1 + kq;
-                        av[s1] = (s1 < nK && r < H) ? col[r * pitch] : 0.0f;
-                    }
-#pragma unroll
-                    for (int s1 = 0; s1 < kU2Run; ++s1)
-                        if (s1 < nK) tmp = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s1], b1[s1], tmp, 0, 0, 0);
-                }
-                if (nK > kU2Run) {
-                    float av[kU2KS - kU2Run];
-#pragma unroll
-                    for (int s1 = kU2Run; s1 < kU2KS; ++s1) {
-                        const int r = rLo + 4 * s1 + kq;
-                        av[s1 - kU2Run] = (s1 < nK && r < H) ? col[r * pitch] : 0.0f;
-                    }
-#pragma unroll
-                    for (int s1 = kU2Run; s1 < kU2KS; ++s1)
-                        if (s1 < nK) {
-                            const int d = d1 + 4 * s1;
-                            tmp = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s1 - kU2Run], sw[min(d < 0 ? -d : d, kU2Guard)], tmp, 0, 0, 0);
-                        }
-                }
-#pragma unroll
-                for (int jj = 0; jj < kU2Reach; ++jj) {
-                    const int q = j - jj;                            // (static)
-                    if (q < 0 || q >= kU2XB) continue;
-                    const int xq = 16 * q;
-#pragma unroll
-                    for (int s2 = 0; s2 < 4; ++s2)                   // k step s2 = the block's columns 4 s2 .. 4 s2 + 3: only those within the reach
-                        if (16 * cb + 4 * s2 + 3 >= xq - 32 - rho && 16 * cb + 4 * s2 <= xq - 17 + rho)      // (wave-uniform)
-                            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(tmp[s2], b2[jj][s2], acc[q], 0, 0, 0);
-                }
-            }
-            }
-        }
-        // layer a + 1 (in registers since the previous iteration) -> the other buffer, which every wave has left (barrier of the previous
-        // iteration); then layer a + 2 is requested
-        if (a + 1 < nA) RTD_U3_STORE((a + 1) & 1);
-        __syncthreads();
-        if (a + 2 < nA) RTD_U3_FETCH(a + 2);
-    }
-    float* out = bevDose + (size_t)k * fc.bevW * fc.bevH;
-#pragma unroll
-    for (int q = 0; q < kU2XB; ++q) {
-        const int ox = 16 * q + li;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int oy = y0 + 4 * kq + reg;
-            if (oy < fc.bevH && ox < fc.bevW) out[(size_t)oy * fc.bevW + ox] = acc[q][reg];
-        }
-    }
-}
-
-#undef RTD_U3_FETCH
-#undef RTD_U3_STORE
-
-// The same once more with the slice cut into blocks of kU4RB row blocks (the reference's water cube: three blocks of four per slice,
-// 570 blocks, two per CU): k_superpose_uniform3's ~190 blocks of twelve waves keep 190 of the 256 CUs busy with three matrix-bound
-// waves per SIMD, and the slices crossed by every layer set the time; here such a slice is spread over three CUs at two waves per
-// SIMD, and the blocks beyond the 512 resident ones are the deep slices with few layers. A block stages, layer by layer, only the
-// ray rows within reach of its own row blocks (<= kU4Rows for radii up to 16: 58 KB; a layer with a larger radius is read straight
-// from global memory), a layer ahead through registers into one LDS buffer.
+// The same two passes with the layers' rows staged in LDS (pass 1's A operands come from LDS, pitch W + 16: the four rows of a k step
+// fall into different banks), for ray grids of up to 128 columns. A block = kU4RB row blocks of one slice (the reference's water cube:
+// three blocks of four per slice, 570 live blocks, two per CU at two waves per SIMD — a block per slice keeps 190 of the 256 CUs busy
+// and the slices crossed by every layer set the time; the blocks beyond the 512 resident ones are the deep slices with few layers).
+// A block stages, layer by layer, only the ray rows within reach of its own row blocks (<= kU4Rows for radii up to 16: 58 KB; a layer
+// with a larger radius is read straight from global memory), a layer ahead through registers into one LDS buffer.
 constexpr int kU4TabLayers = 32;
 // w[ii] of a layer with 1 / (sqrt 2 sigma) = rs in ray units: the integral of the Gaussian over pixel ii (series for narrow pixels, as k_superpose_uniform2)
 __device__ __forceinline__ float u4Weight(int ii, int rho, float rs) {
@@ -663,18 +420,21 @@ __global__ __launch_bounds__(64 * kU4Waves, 2) void k_superpose_uniform4(const f
                         if (16 * jj + 4 * s2 >= 29 - R && 16 * jj + 4 * s2 <= 47 + R) b2[jj][s2] = sw[min(d < 0 ? -d : d, kU2Guard)];
                     }
                 const float* col0 = in + (rLo + kq - rOff) * inPitch + 4 * (li & 3) + (li >> 2);
+                // (read first, choose then: a load under a condition becomes a branch; the rows past the staged ones lie within the kU4Slack
+                //  rows of the buffer. The values of column block cb + 1 — of the pitch's padding after the last — are read ahead of cb's arithmetic)
+                float av[NK], avN[NK];
+#pragma unroll
+                for (int s1 = 0; s1 < NK; ++s1) avN[s1] = col0[4 * s1 * inPitch];
 #pragma unroll
                 for (int j = kU2Reach - 1; j < kU2CB; ++j) {
                     const int cb = j - (kU2Reach - 1);
                     if (cb >= nCB) break;                            // (wave-uniform)
                     f32x4 tmp = {0.0f, 0.0f, 0.0f, 0.0f};
-                    const float* col = col0 + 16 * cb;
-                    float av[NK];
+                    const float* colN = col0 + 16 * (cb + 1);
 #pragma unroll
-                    for (int s1 = 0; s1 < NK; ++s1) {                // (read first, choose then: a load under a condition becomes a branch;
-                        const float v = col[4 * s1 * inPitch];       //  the rows past the staged ones lie within the kU4Slack rows of the buffer)
-                        av[s1] = (rLo + 4 * s1 + kq <= rHi4) ? v : 0.0f;
-                    }
+                    for (int s1 = 0; s1 < NK; ++s1) av[s1] = (rLo + 4 * s1 + kq <= rHi4) ? avN[s1] : 0.0f;
+#pragma unroll
+                    for (int s1 = 0; s1 < NK; ++s1) avN[s1] = colN[4 * s1 * inPitch];
 #pragma unroll
                     for (int s1 = 0; s1 < NK; ++s1) tmp = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s1], b1[s1], tmp, 0, 0, 0);
 #pragma unroll

@@ -141,12 +141,12 @@ def make_field(luts, n, voxel, origin, gantry_deg, spots, pitch, n_layers, seed,
 
 
 def water_cube(luts, n=256, n_layers=20, spots=33, pitch=3.0, seed=1234, gantry_deg=0.0, source_dist=(math.inf, math.inf),
-               steps=512):
+               steps=512, ray_spacing=(1.0, 1.0)):
     """C2 = the reference's WATER_CUBE_TEST (main.cu:39-43,61-62,74-99) for n=256; C1 for n=128, n_layers=1."""
     voxel = 256.0 / n
     ct = np.full((n, n, n), 1000.0, dtype=np.float32)
     origin = (-128.0, -128.0, -256.0 + 150.0)
-    beam = make_field(luts, n, voxel, origin, gantry_deg, spots, pitch, n_layers, seed, source_dist, steps)
+    beam = make_field(luts, n, voxel, origin, gantry_deg, spots, pitch, n_layers, seed, source_dist, steps, ray_spacing)
     return Scenario("water%d_L%d" % (n, n_layers), luts, ct, (voxel,) * 3, [beam],
                     "water cube %d^3, %d layer(s), %dx%d spots" % (n, n_layers, spots, spots))
 

@@ -20,7 +20,13 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     n_layers = int(rng.choice([1, 2, 3, 7, 12, 20])); steps = int(rng.choice([200, 256, 400, 512]))
     diverge = rng.random() < 0.25
     dist = (float(rng.uniform(900, 3000)), float(rng.uniform(900, 3000))) if diverge else (math.inf, math.inf)
-    scn = scenarios.water_cube(synth, n=n, n_layers=n_layers, spots=spots, pitch=pitch, seed=int(rng.integers(1, 9999)), source_dist=dist, steps=steps)
+    fine = rng.random() < 0.25                                          # 0.6 / 0.75 mm rays: batch radii above 16 (rows read from global memory)
+    rs = float(rng.choice([0.6, 0.75])) if fine else 1.0
+    if fine:
+        spots = min(spots, int(100 * rs / pitch))                       # (the ray grid stays within 128 columns: k_superpose_uniform4)
+        spots = max(spots, 2)
+    scn = scenarios.water_cube(synth, n=n, n_layers=n_layers, spots=spots, pitch=pitch, seed=int(rng.integers(1, 9999)), source_dist=dist, steps=steps,
+                               ray_spacing=(rs, rs))
     scn.ct[:] = float(rng.choice([1000.0, 1000.0, 900.0, 1150.0]))       # homogeneous, not necessarily water
     try:
         dose, ref, timing, info = T._compare_field(orc, engine, scn, scn.beams[0])
@@ -31,5 +37,5 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     assert info["uniform_sigma"] == (0 if diverge else 1), (seed, info["uniform_sigma"], diverge)
     n_uni += info["uniform_sigma"]
     n_ok += 1
-    print("seed", seed, "ok", n, spots, pitch, n_layers, steps, "diverging" if diverge else "parallel", "uniform" if info["uniform_sigma"] else "general", flush=True)
+    print("seed", seed, "ok", n, spots, pitch, n_layers, steps, "diverging" if diverge else "parallel", "uniform" if info["uniform_sigma"] else "general", "rays %.2f mm radius %d grid %s" % (rs, info["max_radius"], info["ray_dims"][:2]), flush=True)
 print("all", n_ok, "ok;", n_uni, "through the uniform path")
