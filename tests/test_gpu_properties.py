@@ -53,7 +53,7 @@ def test_exact_linearity_in_spot_weights(engine, synth):
 
 def test_c2_reference_water_cube_full_size(orc, engine, synth):
     """BASELINE.json configs[1]: the reference's WATER_CUBE_TEST, 256^3, 33x33 spots x 20 layers, 512 steps (a water field: the engine
-    takes it through k_superpose_uniform3, the separable superposition on the matrix cores — tests/test_gpu_parity.py checks the path)."""
+    takes it through k_superpose_uniform4, the separable superposition on the matrix cores — tests/test_gpu_parity.py checks the path)."""
     scn = scenarios.water_cube(synth, n=256, n_layers=20)
     ref = orc.compute(scn)
     dose = _dose(engine, scn)
