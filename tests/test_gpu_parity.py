@@ -491,12 +491,14 @@ def test_c1_bev_dose_against_the_reference_cpu_convolution(orc, engine, synth):
         eng.close()
 
 
-@pytest.mark.parametrize("case", ["rows staged in LDS", "wave per row block", "wide ray grid: two strips", "fine rays: radii above 16"])
+@pytest.mark.parametrize("case", ["rows staged in LDS", "wave per row block", "wide ray grid: two strips", "fine rays: radii above 16",
+                                  "forty layers: more than the weight table holds"])
 def test_uniform_sigma_kernels(orc, engine, synth, monkeypatch, case):
     """The two separable-superposition kernels of rtd_uniform.hpp on water fields, every intermediate against the oracle:
     k_superpose_uniform4 (a block per four row blocks of a slice, the layers' rows within reach staged in LDS: ray grids of up to 128
     columns; on 0.6 mm rays the deep layers' radii pass 16 and their rows are read from global memory by the same kernel, through its
-    generic instruction pattern), k_superpose_uniform2 (one wave per row block and strip of 192 columns, no staging: forced with
+    generic instruction pattern; with forty layers the weights of the layers past the block's table of 32 are computed per wave),
+    k_superpose_uniform2 (one wave per row block and strip of 192 columns, no staging: forced with
     RTD_UNIFORM_V2 on the same field, and chosen by the engine for a ray grid of 192 columns, where a slice has two strips)."""
     if case == "wave per row block":
         monkeypatch.setenv("RTD_UNIFORM_V2", "1")
@@ -506,6 +508,8 @@ def test_uniform_sigma_kernels(orc, engine, synth, monkeypatch, case):
         scn = scenarios.water_cube(synth, n=128, n_layers=3, spots=47, pitch=3.0)
     elif case == "fine rays: radii above 16":
         scn = scenarios.water_cube(synth, n=128, n_layers=4, spots=12, pitch=3.0, ray_spacing=(0.6, 0.6))
+    elif case == "forty layers: more than the weight table holds":
+        scn = scenarios.water_cube(synth, n=64, n_layers=40, spots=9, pitch=3.0)      # (the shallow slices are crossed by all 40: kU4TabLayers = 32)
     else:
         scn = scenarios.water_cube(synth, n=128, n_layers=4)
     _, _, _, info = _compare_field(orc, engine, scn, scn.beams[0])
