@@ -938,7 +938,9 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
     // (k_superpose_sweep<true>: its block 0 is the plan): one launch and its gap less on the critical path.
     const bool selfPlan = f->sweepEnabled && !tryUniform && !fc.nuclearCorr && std::getenv("RTD_SEPARATE_KS_PLAN") == nullptr;
     f->selfPlanned = selfPlan;
-    if (!selfPlan) launchK(k_ks_plan, dim3(1), dim3(256), 0, s, nullptr, f->ev[4], ksArgs, fc);
+    // (a field that may be a uniform-sigma one has its 2 x L x S sigma extremes compared by this one block: 1024 threads make that
+    //  three memory round trips instead of ten)
+    if (!selfPlan) launchK(k_ks_plan, dim3(1), dim3(tryUniform ? 1024 : 256), 0, s, nullptr, f->ev[4], ksArgs, fc);
     if (fc.nuclearCorr) {
         const int nPix = (fc.nucW + 2 * kMaxSuperpR) * (fc.nucH + 2 * kMaxSuperpR);
         k_nuc_superpose<<<(nPix + 255) / 256, 256, 0, s>>>((const float*)f->dNucIdd, (const float*)f->dNucRs, (const int*)f->dNucEffT,

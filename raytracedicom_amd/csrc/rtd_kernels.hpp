@@ -1426,7 +1426,7 @@ __device__ inline void ksPlanBody(const KsPlanArgs& ka, const FieldConst& fc, co
         if (stNuc && tid == 0 && sSt.errorFlags) stNuc->errorFlags = sSt.errorFlags;
     }
 }
-__global__ __launch_bounds__(256) void k_ks_plan(KsPlanArgs ka, FieldConst fc) {
+__global__ __launch_bounds__(1024) void k_ks_plan(KsPlanArgs ka, FieldConst fc) {
     __shared__ KsPlanLds lds;
     ksPlanBody(ka, fc, threadIdx.x, blockDim.x, lds);
 }
