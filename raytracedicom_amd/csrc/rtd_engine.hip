@@ -875,7 +875,7 @@ int rtd_field_compute_bev(rtd_handle hh, rtd_field ff) {
                 (const float*)h->dCt, (int)h->ctDims[0], (int)h->ctDims[1], (int)h->ctDims[2], h->lut, f->tracer, fc.W, fc.H, f->dDensity, f->dWepl, f->dIdd,
                 f->dRrl, h->rrlScale, f->dState, (const float*)f->dSegPos);
     }
-    constexpr size_t scanLds = 2 * kScanChunk * 64 * sizeof(float);   // 128 KiB: above the 64 KiB default cap of dynamic LDS
+    constexpr size_t scanLds = 2 * 2 * kScanChunk * 64 * sizeof(float);   // two buffers of 64 KiB: above the 64 KiB default cap of dynamic LDS
     if (!h->scanLdsSet) {
         RTD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_trace_scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scanLds));
         h->scanLdsSet = true;

@@ -469,11 +469,11 @@ __global__ __launch_bounds__(kTdThreads) void k_trace_sample_d(const float* __re
 //   wave 1: cumulHu -> beforeFirstInside (:173-176)        wave 2: hu > 150 -> lastInside (:177-180)
 // (Round 3, measured and dropped: 32 rays per block — 264 blocks instead of 132, the two chains in the halves of one wave. The
 //  kernel is bound by the length of the serial chains, not by per-CU bandwidth: 27 -> 60 us.)
-constexpr int kScanWaves = 16, kScanChunk = 256, kScanPerWave = kScanChunk / kScanWaves;
+constexpr int kScanWaves = 16, kScanChunk = 128, kScanPerWave = kScanChunk / kScanWaves;
 __global__ __launch_bounds__(64 * kScanWaves) void k_trace_scan(const float* __restrict__ huBuf, float* __restrict__ bevCumulSp, int W, int H,
                                                                  unsigned int steps, int* __restrict__ firstInside, int* __restrict__ firstOutside,
                                                                  FieldState* st, float* __restrict__ blockWeplMin, ResetJob reset) {
-    extern __shared__ float sScan[];                                 // [hu, sp][kScanChunk][64]; the next chunk waits in registers
+    extern __shared__ float sScan[];                                 // two buffers [hu, sp][kScanChunk][64]: one is walked and stored while the next chunk is staged into the other
     const int lane = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
     const int ray = blockIdx.x * 64 + lane;
     const size_t memStep = (size_t)W * H;
@@ -483,8 +483,8 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_trace_scan(const float* __r
     stamp();
     // the waves without a serial chain reset the per-layer records, the tile-radius bytes and the dose rectangles (K0)
     if (wv >= 3) resetFieldArrays(reset, ((size_t)blockIdx.x * (kScanWaves - 3) + (wv - 3)) * 64 + lane, (size_t)gridDim.x * (kScanWaves - 3) * 64);
-    auto sHu = [&](int, int i) -> float& { return sScan[i * 64 + lane]; };
-    auto sSp = [&](int, int i) -> float& { return sScan[(kScanChunk + i) * 64 + lane]; };
+    auto sHu = [&](int b, int i) -> float& { return sScan[((2 * b) * kScanChunk + i) * 64 + lane]; };
+    auto sSp = [&](int b, int i) -> float& { return sScan[((2 * b + 1) * kScanChunk + i) * 64 + lane]; };
     float rHu[kScanPerWave], rSp[kScanPerWave];
     auto fetch = [&](unsigned int c0) {                              // this wave's kScanPerWave steps of the chunk starting at c0
 #pragma unroll
@@ -537,6 +537,10 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_trace_scan(const float* __r
         }
         ldsBarrier();                                                // chunk walked
         stamp();
+        // The next chunk goes from the registers into the OTHER buffer first: this wait is for loads issued a walk ago. (With one
+        // buffer the staging came after the stores of the walked chunk, and its wait for the loads — one counter for loads and
+        // stores, in order — stood through the stores' whole latency: 5.4 k cycles per 256-step chunk, clock stamps.)
+        if (c0 + kScanChunk < steps) stage(buf ^ 1, c0 + kScanChunk);
         float wOut[kScanPerWave], hOut[kScanPerWave];                // (all LDS reads first: one round trip, not one per step)
 #pragma unroll
         for (int j = 0; j < kScanPerWave; ++j) { wOut[j] = sSp(buf, wv * kScanPerWave + j); hOut[j] = sHu(buf, wv * kScanPerWave + j); }
@@ -545,21 +549,24 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_trace_scan(const float* __r
             const unsigned int i = c0 + wv * kScanPerWave + j;
             if (i < steps) {
                 if (hOut[j] < 150.0f) beforeFirstInside = max(beforeFirstInside, (int)i);
-                const float wepl = wOut[j];
-                bevCumulSp[ray + (size_t)i * memStep] = wepl;
-                // sliceMinVar<float> (kernel_wrapper.cuh:215-244, launch kernel_wrapper.cu:788), first level: this block's 64 rays;
-                // k_plan takes the minimum over the blocks (one value per block and step instead of a pass over all of WEPL)
-                const float m = waveMin(wepl);
-                if (lane == 0) blockWeplMin[(size_t)blockIdx.x * steps + i] = m;
+                bevCumulSp[ray + (size_t)i * memStep] = wOut[j];
             }
         }
-        stamp();
-        if (c0 + kScanChunk < steps) {
-            ldsBarrier();                                            // chunk stored: the buffer takes the next one
-            stage(buf, c0 + kScanChunk);
-            ldsBarrier();
-            stamp();
+        // sliceMinVar<float> (kernel_wrapper.cuh:215-244, launch kernel_wrapper.cu:788), first level: this block's 64 rays; k_plan takes
+        // the minimum over the blocks (one value per block and step instead of a pass over all of WEPL). Transposed: lane = step, the 64
+        // rays of the step read from the chunk in a rotated order (lane l starts at ray l: 64 banks) — 64 reads and minima per lane and
+        // one coalesced store per wave, against a cross-lane reduction and a one-lane store per step.
+        if (wv >= 2 && wv < 2 + kScanChunk / 64) {
+            const int stepInChunk = (wv - 2) * 64 + lane;
+            const float* col = sScan + (size_t)((2 * buf + 1) * kScanChunk + stepInChunk) * 64;
+            float m = col[lane];
+#pragma unroll 16
+            for (int r = 1; r < 64; ++r) { const float t = col[(lane + r) & 63]; m = t < m ? t : m; }
+            if (c0 + stepInChunk < steps) blockWeplMin[(size_t)blockIdx.x * steps + c0 + stepInChunk] = m;
         }
+        stamp();
+        ldsBarrier();                                                // next chunk staged; this one stored: its buffer is free
+        stamp();
     }
     // the waves' partial maxima meet: [wave][ray] in the (now free) chunk buffer
     ldsBarrier();

@@ -17,10 +17,9 @@ for i in range(3):
     f.compute(d); t, info = f.finish()
 q = f.fetch("scan_debug").reshape(-1, 8).astype(np.float64)
 t0 = q[:, 0].min()
-names = ["start", "chunk 0 staged", "chunk 0 walked", "chunk 0 stored", "chunk 1 staged", "chunk 1 walked", "chunk 1 stored"]
-print("blocks", q.shape[0])
-for i, nm in enumerate(names):
-    print("%-16s mean %9.0f  min %9.0f max %9.0f (ticks since the first block's start)" % (nm, (q[:, i] - t0).mean(), (q[:, i] - t0).min(), (q[:, i] - t0).max()))
-for i in range(1, 7):
+# wave 0 (the WEPL chain) stamps: start, first chunk staged, then per 128-step chunk: walked (after the barrier), its own staging and stores done, past the end barrier
+names = ["start", "chunk 0 staged", "chunk 0 walked", "chunk 0 stored", "barrier 0", "chunk 1 walked", "chunk 1 stored", "barrier 1"]
+print("blocks", q.shape[0], "(shader clocks; stamps of a block's wave 0; the first two of four chunks)")
+for i in range(1, 8):
     print("  phase -> %-16s mean %8.0f max %8.0f" % (names[i], (q[:, i] - q[:, i - 1]).mean(), (q[:, i] - q[:, i - 1]).max()))
 f.destroy(); eng.close()
